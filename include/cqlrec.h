@@ -1,0 +1,207 @@
+/*
+ * cqlrec.h -- C ABI of libcqlrec.so, the MI355X (gfx950) CQL recommender hot path.
+ *
+ * The reference (monkey0head/RePlay_cql @ 2025-02-28 = replay-rec 0.10.0) has NO FFI layer and no CQL model
+ * (SURVEY.md F1-F3): its plug-in boundary is the Python abstract class replay/models/base_rec.py:1202-1335
+ * (Recommender.fit/predict) with the hooks _fit (:376-392) and _predict (:607-637).  The entry points below
+ * are what a `replay/models/cql.py` behind that boundary binds with ctypes; each one cites
+ * the reference code whose role it takes over.  Arithmetic follows SURVEY.md section 8.0 (S1-S7, P1-P4).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / a torch tensor's data_ptr()) unless marked [host];
+ *   - plain pointers and sizes only, no torch types; `stream` is a hipStream_t passed as void* (0 = null stream);
+ *   - all calls are asynchronous on `stream`, allocate nothing, never synchronise: they may be captured in a hipGraph;
+ *   - bf16 tensors are uint16_t bit patterns; matrices are row-major; W1/W2 are stored [out][in];
+ *   - return value: CQLREC_OK, or a negative code with the message available from cqlrec_last_error().
+ */
+#ifndef CQLREC_H
+#define CQLREC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CQLREC_OK 0
+#define CQLREC_ERR_INVALID (-1)
+#define CQLREC_ERR_HIP (-2)
+#define CQLREC_ABI_VERSION 1
+#define CQLREC_SEG_ALIGN 64 /* every parameter segment starts on a multiple of 64 elements */
+
+typedef void* cqlrec_stream;
+
+int cqlrec_abi_version(void);
+const char* cqlrec_last_error(void); /* [host] thread-local message of the last failing call */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Parameter layout (S3).  One flat buffer holds  E_in[(N+1) x d] | E_out[N x d] | b_out[N] | W1[d x d] | b1[d] |
+ * W2[d x d] | b2[d]; theta (fp32), grads, Adam m/v, the target copy and both bf16 shadows share these offsets.
+ * Replaces the nn.Module parameter containers of the torch analogues (replay/models/neuromf.py:37-211).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct cqlrec_layout {
+  int64_t n_items;
+  int32_t d;
+  int32_t reserved;
+  int64_t off_E_in, off_E_out, off_b_out, off_W1, off_b1, off_W2, off_b2;
+  int64_t total; /* elements, padded */
+} cqlrec_layout;
+int cqlrec_layout_make(int64_t n_items, int32_t d, cqlrec_layout* out /* [host] */);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a2/a8  Transition sampler: counter-based, bit-exact with oracle.sample_positions().  Takes the place of the
+ * DataLoader iteration in TorchRecommender.train (replay/models/base_torch_rec.py:78-80).
+ *   k1 = mix64(seed ^ step*0xD1B54A32D192ED03); p = mulhi64(mix64(k1 + slot0 + b), nnz); user = last u with
+ *   offsets[u] <= p; t = p - offsets[u]; act = items[p]; rew = rewards[p]; done = (t == count(u)-1).
+ * --------------------------------------------------------------------------------------------------------- */
+int cqlrec_sample_transitions(const int64_t* offsets, const int32_t* items, const float* rewards, int64_t n_users,
+                              uint64_t seed, uint64_t step, uint64_t slot0, int32_t batch, int32_t* users,
+                              int32_t* tpos, int32_t* act, float* rew, float* done, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a3  Window gather + masked mean (S4 h0).  No reference counterpart (closest: nn.Embedding lookups,
+ * replay/models/neuromf.py:72-73).  State i = the last min(end_i, L) items of users[i] before position
+ * end_i = ends[i] + end_delta  (ends == NULL: end_i = row length, the predict-time state, S7).
+ * Outputs (either may be NULL): h0 fp32 [n x d], h0_b bf16 [n x d], lens int32 [n].
+ * --------------------------------------------------------------------------------------------------------- */
+int cqlrec_gather_pool_fwd(const uint16_t* E_in_b, const int64_t* offsets, const int32_t* items,
+                           const int32_t* users, const int32_t* ends, int32_t end_delta, int64_t n_states,
+                           int32_t L, int32_t d, float* h0, uint16_t* h0_b, int32_t* lens, cqlrec_stream stream);
+/* backward of the above: g_E_in[item] += dh0[i] / len_i for every item of window i (fp32 atomics) */
+int cqlrec_gather_pool_bwd(const float* dh0, const int64_t* offsets, const int32_t* items, const int32_t* users,
+                           const int32_t* ends, int32_t end_delta, int64_t n_states, int32_t L, int32_t d,
+                           float* g_E_in, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a4  One encoder layer  Y = act(X_b W_b^T + bias)  on bf16 MFMA, fp32 accumulate (closest reference code:
+ * MLP.forward, replay/models/neuromf.py:133-145).  Y (fp32) and Y_b (bf16) may each be NULL.
+ * --------------------------------------------------------------------------------------------------------- */
+int cqlrec_linear_bf16(const uint16_t* X_b, const uint16_t* W_b, const float* bias, int64_t rows, int32_t d,
+                       int32_t relu, float* Y, uint16_t* Y_b, cqlrec_stream stream);
+/* fp32 backward of the two-layer encoder on the bf16-valued forward operands.  ws: cqlrec_encoder_bwd_ws_bytes. */
+int64_t cqlrec_encoder_bwd_ws_bytes(int64_t rows, int32_t d);
+int cqlrec_encoder_bwd(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,
+                       const uint16_t* W2_b, int64_t rows, int32_t d, void* ws, int64_t ws_bytes, float* g_W1,
+                       float* g_b1, float* g_W2, float* g_b2, float* dh0, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a5  Full-catalog Q-head, fused with its row reduction; the rows x N score matrix never reaches HBM.
+ * Closest reference code: the catalog-wide Linear + log_softmax of MultVAE (replay/models/mult_vae.py:101,
+ * :275-276).   Q[r][j] = <H_b[r], E_out_b[j]> + b_out[j].
+ *   mode CQLREC_QHEAD_LSE    : out_val[r] = logsumexp_j Q[r][j]; out_nlse2[r] = -out_val[r]*log2(e) (may be NULL)
+ *   mode CQLREC_QHEAD_ARGMAX : out_val[r] = max_j Q[r][j]; out_idx[r] = argmax (ties -> smallest j)
+ * ws: cqlrec_qhead_ws_bytes(rows, n_items, d) bytes of scratch.
+ * --------------------------------------------------------------------------------------------------------- */
+#define CQLREC_QHEAD_LSE 1
+#define CQLREC_QHEAD_ARGMAX 2
+int64_t cqlrec_qhead_ws_bytes(int64_t rows, int64_t n_items, int32_t d);
+int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
+                     int64_t n_items, int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val,
+                     int32_t* out_idx, float* out_nlse2, cqlrec_stream stream);
+
+/* out[r] = <H_b[r], E_b[idx[r]]> + b[idx[r]]   (q_a, the target-net Q(s',a*), and _predict_pairs, a11:
+ * replay/models/base_rec.py:784-823) */
+int cqlrec_gather_dot(const uint16_t* H_b, const uint16_t* E_b, const float* b, const int32_t* idx, int64_t rows,
+                      int32_t d, float* out, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a6  CQL + double-Q TD loss (S5) and its backward.  Reference analogue of the role: the _loss hooks +
+ * loss.backward() (replay/models/base_torch_rec.py:35-37).
+ *   y = rew + gamma (1-done) q_targ;  delta = q_a - y;  loss = inv_batch * sum_b [0.5 delta^2 + alpha (lse - q_a)]
+ *   coef[b] = (delta - alpha) * inv_batch         (inv_batch = 1 / global batch)
+ * loss_out: one float, written (deterministic tree reduction).
+ * --------------------------------------------------------------------------------------------------------- */
+int cqlrec_td_loss(const float* q_a, const float* lse, const float* q_targ, const float* rew, const float* done,
+                   int32_t batch, float gamma, float alpha, float inv_batch, float* coef, float* y,
+                   float* loss_out, cqlrec_stream stream);
+/* dQ = scale * bf16(exp(Q - lse)) + coef * onehot(act)   (scale = alpha * inv_batch), never materialised:
+ *   dH[b]        = scale * sum_j P_b[b][j] E_out_b[j] + coef[b] E_out_b[act[b]]
+ *   g_E_out[j]   = scale * sum_b P_b[b][j] H_b[b]     + sum_{b: act[b]=j} coef[b] H_b[b]        (overwritten)
+ *   g_b_out[j]   = scale * sum_b P[b][j]              + sum_{b: act[b]=j} coef[b]               (overwritten)
+ * nlse2 = -lse*log2(e) from cqlrec_qhead_fwd.  ws: cqlrec_qhead_bwd_ws_bytes. */
+int64_t cqlrec_qhead_bwd_ws_bytes(int64_t batch, int64_t n_items, int32_t d);
+int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                     int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
+                     float scale, void* ws, int64_t ws_bytes, float* dH, float* g_E_out, float* g_b_out,
+                     cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a7  Fused Adam + Polyak target + bf16 shadows over the flat buffer (S6).  Replaces optimizer.step()
+ * (replay/models/base_torch_rec.py:38; torch.optim.Adam at replay/models/neuromf.py:351-355).
+ *   m = b1 m + (1-b1) g;  v = b2 v + ((1-b2) g) g;  theta -= step_size * (m / (sqrt(v)/sqrt_bc2 + eps));
+ *   target = (1-tau) target + tau theta;  theta_b = bf16(theta);  target_b = bf16(target);  g = 0 if zero_grads.
+ * step_size = lr/(1-b1^t), sqrt_bc2 = sqrt(1-b2^t) are computed by the caller in double and passed as float.
+ * --------------------------------------------------------------------------------------------------------- */
+int cqlrec_adam_ema(float* theta, float* grads, float* m, float* v, float* target, uint16_t* theta_b,
+                    uint16_t* target_b, int64_t n, float step_size, float sqrt_bc2, float beta1, float beta2,
+                    float eps, float tau, int32_t zero_grads, cqlrec_stream stream);
+/* dst_b = bf16(src) (shadow refresh after load / init) */
+int cqlrec_cast_bf16(const float* src, uint16_t* dst_b, int64_t n, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a10  All-users top-K scoring (S7).  Takes the place of TorchRecommender._predict's per-user pandas UDF
+ * (replay/models/base_torch_rec.py:120-149) + NeuroMF._predict_by_user's argsort (replay/models/neuromf.py:
+ * 393-438) + _filter_seen / get_top_k_recs (replay/models/base_rec.py:417-464, replay/utils.py:112-127).
+ *   H_b      [n_users x d]  bf16 state vectors (encoder output)
+ *   E_b, b   candidate item table [n_cand x d] bf16 and bias [n_cand]
+ *   item_ids [n_cand] global id of candidate row c (NULL: identity); must be ascending
+ *   seen_off, seen_items: CSR of ascending global item ids to exclude; scored user u uses CSR row
+ *            seen_rows[u] (seen_rows NULL: row u).  seen_off NULL: no filter.
+ * Output, per user: the k best (score desc, item id asc) admissible items: out_idx/out_val [n_users x k]
+ * (padding: -1 / -inf) and out_cnt [n_users] = number of valid entries.
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t cqlrec_topk_ws_bytes(int64_t n_users, int64_t n_cand, int32_t d, int32_t k);
+int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b, int64_t n_cand,
+                      int32_t d, const int32_t* item_ids, const int64_t* seen_off, const int32_t* seen_items,
+                      const int32_t* seen_rows, int32_t k, void* ws, int64_t ws_bytes, int32_t* out_idx,
+                      float* out_val, int32_t* out_cnt, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a8  Whole training step = TorchRecommender._run_train_step (replay/models/base_torch_rec.py:32-39) without
+ * the per-step host sync.  The step is split in two so that a data-parallel caller can all-reduce ctx.grads
+ * (RCCL) between them; losses[] receives one float per step.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct cqlrec_train_ctx {
+  cqlrec_layout layout;
+  /* training set (CSR by user, S2) */
+  const int64_t* offsets;
+  const int32_t* items;
+  const float* rewards;
+  int64_t n_users;
+  /* model state, each `layout.total` elements */
+  float* theta;
+  float* grads;
+  float* adam_m;
+  float* adam_v;
+  float* target;
+  uint16_t* theta_b;
+  uint16_t* target_b;
+  /* hyper-parameters */
+  int32_t batch;        /* transitions per step on this rank (multiple of 32) */
+  int32_t window;       /* L */
+  int32_t world;        /* data-parallel ranks (loss is a mean over batch*world) */
+  int32_t rank;
+  float gamma, alpha, lr, beta1, beta2, eps, tau;
+  uint64_t seed;
+  /* scratch: cqlrec_train_ws_bytes(batch, n_items, d) bytes */
+  void* ws;
+  int64_t ws_bytes;
+} cqlrec_train_ctx;
+int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t d);
+/* sample + forward + loss + backward into ctx->grads (which must be zero on entry; step_update re-zeroes it).
+ * loss_out: device float (may be NULL). */
+int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,
+                              cqlrec_stream stream);
+/* Adam + target + shadows (+ zero grads). `step` is the same 0-based counter. */
+int cqlrec_train_step_update(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
+
+/* Debug/inspection of the step's intermediates inside ctx->ws (device pointers; valid after fwd_bwd). */
+typedef struct cqlrec_train_views {
+  int32_t *users, *tpos, *act, *a_star;
+  float *rew, *done, *q_a, *lse, *q_targ, *y, *coef, *dH, *dh0, *h0_s;
+  uint16_t *hb_s, *hb_sn, *hb_tn;
+} cqlrec_train_views;
+int cqlrec_train_views_get(const cqlrec_train_ctx* ctx /* [host] */, cqlrec_train_views* out /* [host] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CQLREC_H */

@@ -375,7 +375,7 @@ def adam_ema_step(theta, grads, m, v, target, step_t, lr, beta1=0.9, beta2=0.999
     f = np.float32
     step_size, sqrt_bc2 = adam_scalars(step_t, lr, beta1, beta2)
     b1, b2, e, t = f(beta1), f(beta2), f(eps), f(tau)
-    omb1, omb2, omt = f(1.0 - beta1), f(1.0 - beta2), f(1.0 - tau)
+    omb1, omb2, omt = f(1) - b1, f(1) - b2, f(1) - t  # fp32 subtraction, as the kernel does
     m[:] = b1 * m + omb1 * grads
     v[:] = b2 * v + (omb2 * grads) * grads
     denom = np.sqrt(v) / sqrt_bc2 + e

@@ -1,0 +1,125 @@
+"""ctypes binding of libcqlrec.so (the C ABI in include/cqlrec.h).
+
+There is NO fallback: if the HIP library is missing or an entry point is absent, loading raises.  The product path
+never routes through oracle/ or any CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+_LIB_PATH = Path(__file__).resolve().parent / "libcqlrec.so"
+_lib: Optional[C.CDLL] = None
+
+ABI_VERSION = 1
+QHEAD_LSE = 1
+QHEAD_ARGMAX = 2
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class Layout(C.Structure):
+    _fields_ = [
+        ("n_items", i64), ("d", i32), ("reserved", i32),
+        ("off_E_in", i64), ("off_E_out", i64), ("off_b_out", i64), ("off_W1", i64), ("off_b1", i64),
+        ("off_W2", i64), ("off_b2", i64), ("total", i64),
+    ]
+
+    SEGMENTS = ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2")
+
+    def offset(self, name: str) -> int:
+        return int(getattr(self, "off_" + name))
+
+    def shape(self, name: str):
+        n, d = int(self.n_items), int(self.d)
+        return {"E_in": (n + 1, d), "E_out": (n, d), "b_out": (n,), "W1": (d, d), "b1": (d,), "W2": (d, d),
+                "b2": (d,)}[name]
+
+
+class TrainCtx(C.Structure):
+    _fields_ = [
+        ("layout", Layout),
+        ("offsets", vp), ("items", vp), ("rewards", vp), ("n_users", i64),
+        ("theta", vp), ("grads", vp), ("adam_m", vp), ("adam_v", vp), ("target", vp), ("theta_b", vp),
+        ("target_b", vp),
+        ("batch", i32), ("window", i32), ("world", i32), ("rank", i32),
+        ("gamma", f32), ("alpha", f32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("tau", f32),
+        ("seed", u64),
+        ("ws", vp), ("ws_bytes", i64),
+    ]
+
+
+class TrainViews(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "users", "tpos", "act", "a_star", "rew", "done", "q_a", "lse", "q_targ", "y", "coef", "dH", "dh0", "h0_s",
+        "hb_s", "hb_sn", "hb_tn")]
+
+
+# name -> (restype, argtypes); every symbol include/cqlrec.h declares
+SIGNATURES = {
+    "cqlrec_abi_version": (i32, []),
+    "cqlrec_last_error": (C.c_char_p, []),
+    "cqlrec_layout_make": (i32, [i64, i32, C.POINTER(Layout)]),
+    "cqlrec_sample_transitions": (i32, [vp, vp, vp, i64, u64, u64, u64, i32, vp, vp, vp, vp, vp, vp]),
+    "cqlrec_gather_pool_fwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp]),
+    "cqlrec_gather_pool_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp]),
+    "cqlrec_linear_bf16": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
+    "cqlrec_encoder_bwd_ws_bytes": (i64, [i64, i32]),
+    "cqlrec_encoder_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "cqlrec_qhead_ws_bytes": (i64, [i64, i64, i32]),
+    "cqlrec_qhead_fwd": (i32, [vp, i64, vp, vp, i64, i32, i32, vp, i64, vp, vp, vp, vp]),
+    "cqlrec_gather_dot": (i32, [vp, vp, vp, vp, i64, i32, vp, vp]),
+    "cqlrec_td_loss": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp]),
+    "cqlrec_qhead_bwd_ws_bytes": (i64, [i64, i64, i32]),
+    "cqlrec_qhead_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp, i64, i32, f32, vp, i64, vp, vp, vp, vp]),
+    "cqlrec_adam_ema": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp]),
+    "cqlrec_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "cqlrec_topk_ws_bytes": (i64, [i64, i64, i32, i32]),
+    "cqlrec_score_topk": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, vp]),
+    "cqlrec_train_ws_bytes": (i64, [i32, i64, i32]),
+    "cqlrec_train_step_fwd_bwd": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
+    "cqlrec_train_step_update": (i32, [C.POINTER(TrainCtx), u64, vp]),
+    "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), C.POINTER(TrainViews)]),
+}
+
+
+class CqlrecError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise -- never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise CqlrecError(
+            f"{_LIB_PATH} is missing: build it with `python -m replay_cql_amd.build` (hipcc --offload-arch=gfx950). "
+            "replay_cql_amd has no CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:  # pragma: no cover
+            raise CqlrecError(f"{_LIB_PATH} does not export {name}; rebuild it") from exc
+        fn.restype, fn.argtypes = res, args
+    if lib.cqlrec_abi_version() != ABI_VERSION:
+        raise CqlrecError(f"libcqlrec ABI {lib.cqlrec_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().cqlrec_last_error().decode("utf-8", "replace")
+        raise CqlrecError(f"{what or 'cqlrec'} failed (rc={rc}): {msg}")
+
+
+def make_layout(n_items: int, d: int) -> Layout:
+    lay = Layout()
+    check(load().cqlrec_layout_make(int(n_items), int(d), C.byref(lay)), "layout_make")
+    return lay

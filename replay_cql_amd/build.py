@@ -1,0 +1,64 @@
+"""Build recipe for libcqlrec.so (HIP, gfx950 only).  `python -m replay_cql_amd.build` or __graft_entry__.build().
+
+The library is built IN-TREE (replay_cql_amd/libcqlrec.so) so that it travels with the repo snapshot to the GPU box;
+it is git-ignored.  hipcc cross-compiles for gfx950 without a GPU present."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libcqlrec.so"
+SOURCES = ["misc.hip", "qhead.hip", "topk.hip", "train.hip"]
+# misc.hip holds the Adam kernel whose expression order is normative: no fma contraction anywhere in that file
+EXTRA = {"misc.hip": ["-ffp-contract=off"]}
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def _stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "cqlrec.h", Path(__file__)]
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not _stale():
+        return LIB
+    hipcc = _hipcc()
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+    def compile_one(src: str) -> Path:
+        obj = objdir / (src + ".o")
+        cmd = common + EXTRA.get(src, []) + ["-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,273 @@
+"""CQLCore: arrays-in / arrays-out host driver of the HIP hot path (no Spark, no pandas).
+
+torch is plumbing only here: it owns device memory, the HIP stream and (for data parallelism) the RCCL process
+group.  Every arithmetic step of fit and predict is a libcqlrec.so kernel reached through the C ABI
+(include/cqlrec.h); there is no CPU or torch fallback -- a missing library raises (see _native.load).
+
+Role in the reference's structure: this is what the body of a `CQL._fit` / `CQL._predict` calls where
+NeuroMF calls `TorchRecommender.train` (replay/models/base_torch_rec.py:57-98) and the per-user pandas UDF
+(replay/models/base_torch_rec.py:120-149)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+@dataclass
+class CQLHyper:
+    d: int = 128
+    window: int = 50
+    batch: int = 4096
+    gamma: float = 0.99
+    alpha: float = 1.0
+    lr: float = 1e-3
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    tau: float = 0.005
+    seed: int = 0
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class CQLCore:
+    """Device-resident CQL model + trainer + scorer for one GPU (one process per GPU under data parallelism)."""
+
+    def __init__(self, n_items: int, hyper: Optional[CQLHyper] = None, device: Optional[torch.device] = None,
+                 rank: int = 0, world: int = 1, process_group=None, init_seed: int = 7):
+        self.lib = N.load()
+        if not torch.cuda.is_available():
+            raise N.CqlrecError("CQLCore needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.hyper = hyper or CQLHyper()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.rank, self.world, self.pg = int(rank), int(world), process_group
+        self.n_items = int(n_items)
+        self.layout = N.make_layout(self.n_items, self.hyper.d)
+        P = int(self.layout.total)
+        dev = self.device
+        self.theta = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.target = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.theta_b = torch.zeros(P, dtype=torch.bfloat16, device=dev)
+        self.target_b = torch.zeros(P, dtype=torch.bfloat16, device=dev)
+        self.step = 0
+        self._csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        self._ws: Optional[torch.Tensor] = None
+        self._ctx: Optional[N.TrainCtx] = None
+        self.init_params(init_seed)
+
+    # ------------------------------------------------------------------ parameters
+    def segment(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        shp = self.layout.shape(name)
+        off = self.layout.offset(name)
+        return flat[off: off + int(np.prod(shp))].view(*shp)
+
+    def init_params(self, seed: int = 7) -> None:
+        """E_in, E_out ~ N(0, 1/d); W ~ xavier_normal; biases 0; PAD row 0."""
+        d, n = self.hyper.d, self.n_items
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        flat = torch.zeros(int(self.layout.total), dtype=torch.float32)
+        for name, std in (("E_in", 1.0 / math.sqrt(d)), ("E_out", 1.0 / math.sqrt(d)),
+                          ("W1", math.sqrt(2.0 / (2 * d))), ("W2", math.sqrt(2.0 / (2 * d)))):
+            shp = self.layout.shape(name)
+            off = self.layout.offset(name)
+            rows = n if name == "E_in" else shp[0]
+            flat[off: off + rows * shp[1]] = torch.randn(rows * shp[1], generator=g) * std
+        self.load_flat(flat)
+
+    def load_flat(self, theta, target=None, adam_m=None, adam_v=None, step: int = 0) -> None:
+        """Install fp32 masters (numpy or torch, length layout.total) and refresh the bf16 shadows on device."""
+        def put(dst, src):
+            src = torch.as_tensor(np.asarray(src) if not torch.is_tensor(src) else src, dtype=torch.float32)
+            if src.numel() != dst.numel():
+                raise ValueError(f"flat buffer has {src.numel()} elements, layout needs {dst.numel()}")
+            dst.copy_(src.to(self.device))
+        put(self.theta, theta)
+        put(self.target, theta if target is None else target)
+        self.adam_m.zero_() if adam_m is None else put(self.adam_m, adam_m)
+        self.adam_v.zero_() if adam_v is None else put(self.adam_v, adam_v)
+        self.grads.zero_()
+        self.step = int(step)
+        self.refresh_shadows()
+
+    def refresh_shadows(self) -> None:
+        P = int(self.layout.total)
+        N.check(self.lib.cqlrec_cast_bf16(_ptr(self.theta), _ptr(self.theta_b), P, _stream()), "cast_bf16")
+        N.check(self.lib.cqlrec_cast_bf16(_ptr(self.target), _ptr(self.target_b), P, _stream()), "cast_bf16")
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"theta": self.theta.cpu(), "target": self.target.cpu(), "adam_m": self.adam_m.cpu(),
+                "adam_v": self.adam_v.cpu(), "step": self.step, "n_items": self.n_items,
+                "hyper": asdict(self.hyper)}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        self.load_flat(sd["theta"], sd["target"], sd["adam_m"], sd["adam_v"], int(sd["step"]))
+
+    # ------------------------------------------------------------------ training
+    def set_log(self, offsets, items, rewards) -> None:
+        """CSR by user (S2): offsets int64[U+1], items int32[nnz], rewards float32[nnz] (numpy or torch)."""
+        def dev(x, dt):
+            t = torch.as_tensor(np.ascontiguousarray(x) if not torch.is_tensor(x) else x)
+            return t.to(device=self.device, dtype=dt).contiguous()
+        offsets, items, rewards = dev(offsets, torch.int64), dev(items, torch.int32), dev(rewards, torch.float32)
+        if offsets.numel() < 2 or int(offsets[-1]) != items.numel() or items.numel() != rewards.numel():
+            raise ValueError("inconsistent CSR: offsets[-1] must equal len(items) == len(rewards) and U >= 1")
+        if items.numel() == 0:
+            raise ValueError("empty log")
+        self._csr = (offsets, items, rewards)
+        self._ctx = None
+
+    def _train_ctx(self) -> N.TrainCtx:
+        if self._ctx is not None:
+            return self._ctx
+        if self._csr is None:
+            raise RuntimeError("set_log() must be called before training")
+        h = self.hyper
+        need = int(self.lib.cqlrec_train_ws_bytes(h.batch, self.n_items, h.d))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        offsets, items, rewards = self._csr
+        c = N.TrainCtx()
+        c.layout = self.layout
+        c.offsets, c.items, c.rewards = _ptr(offsets), _ptr(items), _ptr(rewards)
+        c.n_users = offsets.numel() - 1
+        c.theta, c.grads, c.adam_m, c.adam_v = _ptr(self.theta), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v)
+        c.target, c.theta_b, c.target_b = _ptr(self.target), _ptr(self.theta_b), _ptr(self.target_b)
+        c.batch, c.window, c.world, c.rank = h.batch, h.window, self.world, self.rank
+        c.gamma, c.alpha, c.lr, c.beta1, c.beta2, c.eps, c.tau = h.gamma, h.alpha, h.lr, h.beta1, h.beta2, h.eps, h.tau
+        c.seed = h.seed
+        c.ws, c.ws_bytes = _ptr(self._ws), self._ws.numel()
+        self._ctx = c
+        return c
+
+    def forward_backward(self, loss_out: Optional[torch.Tensor] = None) -> None:
+        """Sample + forward + loss + backward of global step `self.step` into self.grads (async)."""
+        c = self._train_ctx()
+        N.check(self.lib.cqlrec_train_step_fwd_bwd(C.byref(c), self.step, _ptr(loss_out), _stream()), "train_step_fwd_bwd")
+
+    def apply_update(self) -> None:
+        c = self._train_ctx()
+        N.check(self.lib.cqlrec_train_step_update(C.byref(c), self.step, _stream()), "train_step_update")
+        self.step += 1
+
+    def allreduce_grads(self) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def train(self, n_steps: int) -> torch.Tensor:
+        """n_steps CQL steps; returns the per-step (rank-local share of the) loss as a device tensor -- no host sync
+        inside the loop (cf. loss.item() per step at replay/models/base_torch_rec.py:39)."""
+        losses = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=self.device)
+        for i in range(n_steps):
+            self.forward_backward(losses[i:i + 1])
+            self.allreduce_grads()
+            self.apply_update()
+        if self.world > 1 and n_steps > 0:
+            import torch.distributed as dist
+            dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=self.pg)
+        return losses[:n_steps]
+
+    def views(self) -> Dict[str, torch.Tensor]:
+        """Intermediates of the last forward_backward (tests / debugging).  Copies, synchronises."""
+        c = self._train_ctx()
+        v = N.TrainViews()
+        N.check(self.lib.cqlrec_train_views_get(C.byref(c), C.byref(v)), "train_views_get")
+        B, d = self.hyper.batch, self.hyper.d
+        torch.cuda.synchronize(self.device)
+        ws = self._ws
+        base = ws.data_ptr()
+
+        def view(name, dtype, shape):
+            nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+            off = getattr(v, name) - base
+            return ws[off: off + nbytes].view(dtype).view(*shape).clone()
+        out = {n: view(n, torch.int32, (B,)) for n in ("users", "tpos", "act", "a_star")}
+        out.update({n: view(n, torch.float32, (B,)) for n in ("rew", "done", "q_a", "lse", "q_targ", "y", "coef")})
+        out.update({n: view(n, torch.float32, (B, d)) for n in ("dH", "dh0", "h0_s")})
+        out.update({n: view(n, torch.bfloat16, (B, d)) for n in ("hb_s", "hb_sn", "hb_tn")})
+        return out
+
+    # ------------------------------------------------------------------ inference
+    def encode(self, offsets: torch.Tensor, items: torch.Tensor, users: torch.Tensor,
+               ends: Optional[torch.Tensor] = None, end_delta: int = 0, use_target: bool = False) -> torch.Tensor:
+        """bf16 state vectors h for (user, end) states; ends=None -> the user's whole history (predict-time state)."""
+        h, lay = self.hyper, self.layout
+        n = users.numel()
+        flat_b = self.target_b if use_target else self.theta_b
+        flat = self.target if use_target else self.theta
+        h0b = torch.empty((n, h.d), dtype=torch.bfloat16, device=self.device)
+        zb = torch.empty_like(h0b)
+        hb = torch.empty_like(h0b)
+        s = _stream()
+        eb = flat_b.data_ptr()
+        N.check(self.lib.cqlrec_gather_pool_fwd(eb + 2 * lay.off_E_in, _ptr(offsets), _ptr(items), _ptr(users), _ptr(ends),
+                                                end_delta, n, h.window, h.d, None, _ptr(h0b), None, s), "gather_pool_fwd")
+        fp = flat.data_ptr()
+        N.check(self.lib.cqlrec_linear_bf16(_ptr(h0b), eb + 2 * lay.off_W1, fp + 4 * lay.off_b1, n, h.d, 1, None,
+                                            _ptr(zb), s), "linear_bf16")
+        N.check(self.lib.cqlrec_linear_bf16(_ptr(zb), eb + 2 * lay.off_W2, fp + 4 * lay.off_b2, n, h.d, 0, None,
+                                            _ptr(hb), s), "linear_bf16")
+        return hb
+
+    def score_topk(self, hb: torch.Tensor, k: int, cand_items: Optional[torch.Tensor] = None,
+                   seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
+                   chunk: int = 32768) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Top-k (score desc, item id asc) for the state vectors hb.  cand_items: ascending int32 global ids (None =
+        whole catalog).  seen = (offsets int64, ascending item ids int32) CSR; seen_rows maps hb rows to CSR rows."""
+        h, lay = self.hyper, self.layout
+        n = hb.shape[0]
+        eb, fp = self.theta_b.data_ptr(), self.theta.data_ptr()
+        if cand_items is None:
+            E_ptr, b_ptr, n_cand, ids_ptr = eb + 2 * lay.off_E_out, fp + 4 * lay.off_b_out, self.n_items, None
+            keep = ()
+        else:  # compact the candidate rows once (plumbing: a row gather)
+            ci = cand_items.to(device=self.device, dtype=torch.int64)
+            E_sub = self.segment(self.theta_b, "E_out").index_select(0, ci).contiguous()
+            b_sub = self.segment(self.theta, "b_out").index_select(0, ci).contiguous()
+            ids = ci.to(torch.int32).contiguous()
+            E_ptr, b_ptr, n_cand, ids_ptr = E_sub.data_ptr(), b_sub.data_ptr(), ids.numel(), ids.data_ptr()
+            keep = (E_sub, b_sub, ids)
+        out_idx = torch.empty((n, k), dtype=torch.int32, device=self.device)
+        out_val = torch.empty((n, k), dtype=torch.float32, device=self.device)
+        out_cnt = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if n == 0:
+            return out_idx, out_val, out_cnt
+        chunk = max(1, min(chunk, n))
+        ws_bytes = int(self.lib.cqlrec_topk_ws_bytes(chunk, n_cand, h.d, k))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        s = _stream()
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            rows_ptr = None if seen_rows is None else seen_rows.data_ptr() + 4 * lo
+            N.check(self.lib.cqlrec_score_topk(
+                hb.data_ptr() + 2 * h.d * lo, hi - lo, E_ptr, b_ptr, n_cand, h.d, ids_ptr,
+                None if seen is None else _ptr(seen[0]), None if seen is None else _ptr(seen[1]), rows_ptr, k,
+                _ptr(ws), ws_bytes, out_idx.data_ptr() + 4 * k * lo, out_val.data_ptr() + 4 * k * lo,
+                out_cnt.data_ptr() + 4 * lo, s), "score_topk")
+        del keep
+        return out_idx, out_val, out_cnt
+
+    def pair_scores(self, hb: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
+        """relevance of (hb[i], item_ids[i]) pairs (a11)."""
+        h, lay = self.hyper, self.layout
+        out = torch.empty((hb.shape[0],), dtype=torch.float32, device=self.device)
+        N.check(self.lib.cqlrec_gather_dot(_ptr(hb), self.theta_b.data_ptr() + 2 * lay.off_E_out,
+                                           self.theta.data_ptr() + 4 * lay.off_b_out, _ptr(item_ids), hb.shape[0], h.d,
+                                           _ptr(out), _stream()), "gather_dot")
+        return out

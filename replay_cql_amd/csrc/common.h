@@ -1,0 +1,88 @@
+// Shared device/host helpers for the cqlrec HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/cqlrec.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 accumulator (16 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+#define CQL_WAVE 64
+#define CQL_LOG2E 1.4426950408889634f
+#define CQL_LN2 0.6931471805599453f
+#define NEG_INF_F (-__builtin_inff())
+
+// ---- error plumbing (host) ---------------------------------------------------------------------------------
+void cql_set_error(const char* fmt, ...);
+#define CQL_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      cql_set_error(__VA_ARGS__);         \
+      return CQLREC_ERR_INVALID;          \
+    }                                     \
+  } while (0)
+#define CQL_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      cql_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return CQLREC_ERR_HIP;                                                \
+    }                                                                       \
+  } while (0)
+
+static inline int cql_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE; NaN stays NaN) -- identical to the oracle's RNE on finite values
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf16_round_f32(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+// 8 bf16 packed in a uint4 -> 8 floats
+__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float (&o)[8]) {
+  o[0] = __uint_as_float(v.x << 16);
+  o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+  o[2] = __uint_as_float(v.y << 16);
+  o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  o[4] = __uint_as_float(v.z << 16);
+  o[5] = __uint_as_float(v.z & 0xFFFF0000u);
+  o[6] = __uint_as_float(v.w << 16);
+  o[7] = __uint_as_float(v.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+// ---- MFMA 32x32x16 bf16 fragment geometry (cdna_hip_programming.md section 3) ------------------------------
+//  A: lane l holds A[row l&31][k = 8*(l>>5) + j], j=0..7      B: lane l holds B[k = 8*(l>>5)+j][col l&31]
+//  C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+__device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// XOR swizzle of the 16-byte chunk index inside an LDS row of D bf16 so that ds_read_b128 by 16 lanes with
+// distinct rows (mod 16) and equal chunk is bank-conflict free (T2).  D=64: rows are 128 B (two per bank row).
+template <int D>
+__device__ __forceinline__ int swz_chunk(int row, int ch) {
+  if constexpr (D == 64) return ch ^ ((row >> 1) & 7);
+  else return ch ^ (row & 15);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// order-preserving map float -> uint32 (larger float <=> larger key; -inf smallest)
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}

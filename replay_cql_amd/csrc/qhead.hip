@@ -1,0 +1,549 @@
+// Full-catalog Q-head on bf16 MFMA (v_mfma_f32_32x32x16_bf16), fused with its reductions so that the
+// rows x N score matrix never reaches HBM.  One streaming skeleton serves five modes:
+//
+//   owner entity  = rows whose fragments stay in registers for the whole kernel (MFMA B operand, on the lane)
+//   streamed entity = rows that flow HBM -> LDS (XOR-swizzled, double-buffered) and are the MFMA A operand
+//
+//   LSE / ARGMAX / TILEMAX : owner = states, streamed = items.   S[item][state] = E_out_b[item] . H_b[state] + b[item]
+//        the per-state reduction over items is in-lane (16 registers) + one lane^32 exchange at the end.
+//   BWD_DH : owner = states, streamed = items.   P = exp2(S*log2e - lse*log2e);  dH^T[f][state] += E_out_b^T P
+//   BWD_DE : owner = items,  streamed = states.  P likewise;                     dE^T[f][item]  += H_b^T P
+//        In both backward modes the 32x32 accumulator of S is converted to bf16 in registers and fed straight back
+//        as the B operand of the second MFMA (k-order = accumulator row order); the A operand is the transposed
+//        read (ds_read_b64_tr_b16) of the very tile already in LDS -- no second copy, no P in LDS or HBM.
+//
+// The streamed range is cut into `nsplit` slices; slice partials are merged by tiny finalize/reduce kernels
+// (deterministic order).  blockIdx % nsplit = slice, so the blocks of one XCD (blockIdx % 8) share few slices.
+#include "qhead_internal.h"
+
+template <int D>
+struct QCfg {
+  static constexpr int CPR = D / 8;                      // 16-byte chunks per row
+  static constexpr int ROWB = D * 2;                     // bytes per row
+  static constexpr int KS = D / 16;                      // MFMA k-steps per dot product
+  static constexpr int TI = (D == 256) ? 32 : QS_TI;    // streamed rows per stage (64 KiB static LDS limit)
+  static constexpr int STAGE_BYTES = TI * ROWB;
+  static constexpr int NLD = STAGE_BYTES / 16 / 256;     // 16-byte chunks per thread per stage
+};
+
+#define NEG_INF (-__builtin_inff())
+
+template <int D, int SPW, int MODE>
+__global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
+  using C = QCfg<D>;
+  constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE);
+  constexpr int FT = D / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_tile[2][C::STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) float lds_sc[2][C::TI];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int split = blockIdx.x % a.nsplit;
+  const int64_t rblk = blockIdx.x / a.nsplit;
+  const int64_t res0 = (rblk * 4 + wave) * (32 * SPW);
+  const int64_t s_begin = (int64_t)split * a.split_rows;
+  const int64_t s_end = (s_begin + a.split_rows < a.n_str) ? (s_begin + a.split_rows) : a.n_str;
+  const int nstage = (s_end > s_begin) ? (int)((s_end - s_begin + C::TI - 1) / C::TI) : 0;
+
+  // ---- resident fragments ---------------------------------------------------------------------------------
+  bf16x8 rf[SPW][C::KS];
+  float rs[SPW];  // per-owner scalar (BWD_DH: -lse*log2e of the state; BWD_DE: bias of the item)
+#pragma unroll
+  for (int g = 0; g < SPW; ++g) {
+    int64_t row = res0 + g * 32 + r;
+    if (row >= a.n_res) row = a.n_res - 1;
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s)
+      rf[g][s] = *reinterpret_cast<const bf16x8*>(a.res + row * D + 16 * s + 8 * h);
+    rs[g] = BWD ? a.res_scalar[row] : 0.f;
+  }
+
+  // ---- per-mode state -------------------------------------------------------------------------------------
+  float st_a[SPW], st_b[SPW];
+  int st_i[SPW];
+#pragma unroll
+  for (int g = 0; g < SPW; ++g) {
+    st_a[g] = NEG_INF;      // running max (LSE, ARGMAX, TILEMAX group max)
+    st_b[g] = 0.f;          // running sum (LSE) / column sum of P (BWD_DE)
+    st_i[g] = 0x7FFFFFFF;   // argmax
+  }
+  f32x16 y[BWD ? SPW : 1][BWD ? FT : 1];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int g = 0; g < SPW; ++g)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[g][ft][i] = 0.f;
+  }
+
+  // ---- stage staging --------------------------------------------------------------------------------------
+  uint4 pre[C::NLD];
+  float sc_pre = NEG_INF;
+  auto issue = [&](int stage) {
+    const int64_t t0 = s_begin + (int64_t)stage * C::TI;
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / C::CPR, ch = c % C::CPR;
+      int64_t srow = t0 + row;
+      if (srow >= a.n_str) srow = a.n_str - 1;
+      pre[i] = *reinterpret_cast<const uint4*>(a.str + srow * D + ch * 8);
+    }
+    if (tid < C::TI) {
+      const int64_t srow = t0 + tid;
+      sc_pre = (srow < s_end) ? a.str_scalar[srow] : NEG_INF;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < C::NLD; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / C::CPR, ch = c % C::CPR;
+      *reinterpret_cast<uint4*>(&lds_tile[buf][row * C::ROWB + swz_chunk<D>(row, ch) * 16]) = pre[i];
+    }
+    if (tid < C::TI) lds_sc[buf][tid] = sc_pre;
+  };
+
+  // transposed-read lane geometry (T10): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
+  const int tr_fsub = ((lane >> 4) & 1) * 16, tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+
+  if (nstage > 0) {
+    issue(0);
+    commit(0);
+  }
+  __syncthreads();
+
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int buf = stage & 1;
+    if (stage + 1 < nstage) issue(stage + 1);
+
+#pragma unroll
+    for (int it = 0; it < C::TI / 32; ++it) {
+      const int trow = it * 32;
+      const int64_t tile_row0 = s_begin + (int64_t)stage * C::TI + trow;  // global streamed row of tile row 0
+      if (tile_row0 >= s_end) continue;
+      // 16 per-register scalars of the streamed rows this lane's accumulator registers correspond to
+      f32x16 sv;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&lds_sc[buf][trow + 8 * q + 4 * h]);
+        sv[4 * q + 0] = t4.x;
+        sv[4 * q + 1] = t4.y;
+        sv[4 * q + 2] = t4.z;
+        sv[4 * q + 3] = t4.w;
+      }
+      f32x16 acc[SPW];
+#pragma unroll
+      for (int g = 0; g < SPW; ++g) {
+        if constexpr (MODE == QM_BWD_DE) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[g][i] = rs[g];
+        } else {
+          acc[g] = sv;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(
+            &lds_tile[buf][(trow + r) * C::ROWB + swz_chunk<D>(trow + r, 2 * s + h) * 16]);
+#pragma unroll
+        for (int g = 0; g < SPW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, rf[g][s], acc[g], 0, 0, 0);
+      }
+
+      // ---------------- epilogues --------------------------------------------------------------------------
+      if constexpr (MODE == QM_LSE) {
+#pragma unroll
+        for (int g = 0; g < SPW; ++g) {
+          float tmax = acc[g][0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[g][i]);
+          const float mn = fmaxf(st_a[g], tmax);
+          const float ms = (mn == NEG_INF) ? 0.f : mn;
+          const float off = -ms * CQL_LOG2E;
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sum += fast_exp2(fmaf(acc[g][i], CQL_LOG2E, off));
+          st_b[g] = st_b[g] * fast_exp2(fmaf(st_a[g], CQL_LOG2E, off)) + sum;
+          st_a[g] = mn;
+        }
+      } else if constexpr (MODE == QM_ARGMAX) {
+#pragma unroll
+        for (int g = 0; g < SPW; ++g) {
+          float tmax = acc[g][0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[g][i]);
+          const bool upd = tmax > st_a[g];
+          if (__any(upd)) {
+            int ii = 15;
+#pragma unroll
+            for (int i = 14; i >= 0; --i) ii = (acc[g][i] == tmax) ? i : ii;
+            if (upd) {
+              st_a[g] = tmax;
+              st_i[g] = (int)(tile_row0 + mfma_row(ii, h));
+            }
+          }
+        }
+      } else if constexpr (MODE == QM_TILEMAX) {
+        const int64_t tile_idx = tile_row0 >> 5;
+        const bool flush = ((tile_idx + 1) % a.tg == 0) || (tile_row0 + 32 >= s_end);
+#pragma unroll
+        for (int g = 0; g < SPW; ++g) {
+          float tmax = acc[g][0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[g][i]);
+          st_a[g] = fmaxf(st_a[g], tmax);
+          if (flush) {
+            const float v = fmaxf(st_a[g], __shfl_xor(st_a[g], 32));
+            const int64_t row = res0 + g * 32 + r;
+            if (h == 0 && row < a.n_res) a.tilemax[(tile_idx / a.tg) * a.n_res + row] = v;
+            st_a[g] = NEG_INF;
+          }
+        }
+      } else {  // backward modes
+        bf16x8 pf[SPW][2];
+#pragma unroll
+        for (int g = 0; g < SPW; ++g) {
+          float p[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float off = (MODE == QM_BWD_DH) ? rs[g] : sv[i];
+            p[i] = fast_exp2(fmaf(acc[g][i], CQL_LOG2E, off));
+          }
+          if constexpr (MODE == QM_BWD_DE) {
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cs += p[i];
+            st_b[g] += cs;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pf[g][0][j] = (__bf16)p[j];
+            pf[g][1][j] = (__bf16)p[8 + j];
+          }
+        }
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 af;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int row = trow + 16 * s2 + 8 * jj + 4 * h + tr_q;
+              const int col = ft * 32 + tr_fsub + 4 * tr_p;
+              const unsigned char* p8 =
+                  &lds_tile[buf][row * C::ROWB + swz_chunk<D>(row, col >> 3) * 16 + (tr_p & 1) * 8];
+              const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p8);
+              af[4 * jj + 0] = t4[0];
+              af[4 * jj + 1] = t4[1];
+              af[4 * jj + 2] = t4[2];
+              af[4 * jj + 3] = t4[3];
+            }
+#pragma unroll
+            for (int g = 0; g < SPW; ++g)
+              y[g][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[g][s2], y[g][ft], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    if (stage + 1 < nstage) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- write partials -------------------------------------------------------------------------------------
+#pragma unroll
+  for (int g = 0; g < SPW; ++g) {
+    const int64_t row = res0 + g * 32 + r;
+    const bool ok = row < a.n_res;
+    const int64_t pidx = (int64_t)split * a.n_res + row;
+    if constexpr (MODE == QM_LSE) {
+      const float m2 = __shfl_xor(st_a[g], 32), l2 = __shfl_xor(st_b[g], 32);
+      const float M = fmaxf(st_a[g], m2);
+      const float ms = (M == NEG_INF) ? 0.f : M;
+      const float Lsum = st_b[g] * fast_exp2((st_a[g] - ms) * CQL_LOG2E) + l2 * fast_exp2((m2 - ms) * CQL_LOG2E);
+      if (ok && h == 0) {
+        a.part_a[pidx] = M;
+        a.part_b[pidx] = Lsum;
+      }
+    } else if constexpr (MODE == QM_ARGMAX) {
+      const float v2 = __shfl_xor(st_a[g], 32);
+      const int i2 = __shfl_xor(st_i[g], 32);
+      const bool take2 = (v2 > st_a[g]) || (v2 == st_a[g] && i2 < st_i[g]);
+      if (ok && h == 0) {
+        a.part_a[pidx] = take2 ? v2 : st_a[g];
+        a.part_i[pidx] = take2 ? i2 : st_i[g];
+      }
+    } else if constexpr (BWD) {
+      if (ok) {
+        float* dst = a.slab + pidx * D;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + ft * 32 + 8 * q + 4 * h) =
+                make_float4(y[g][ft][4 * q + 0], y[g][ft][4 * q + 1], y[g][ft][4 * q + 2], y[g][ft][4 * q + 3]);
+      }
+      if constexpr (MODE == QM_BWD_DE) {
+        const float cs = st_b[g] + __shfl_xor(st_b[g], 32);
+        if (ok && h == 0) a.slab_cs[pidx] = cs;
+      }
+    }
+  }
+}
+
+// =============================================================================================================
+// split selection + launch
+// =============================================================================================================
+QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows) {
+  QSplit s;
+  s.rblks = (n_res + 128 * spw - 1) / (128 * spw);
+  const int64_t units = (n_str + unit_rows - 1) / unit_rows;
+  int64_t want = (QS_TARGET_BLOCKS + s.rblks - 1) / s.rblks;
+  int64_t max_split = units / 2;  // at least two units of streamed rows per slice
+  if (max_split < 1) max_split = 1;
+  if (want > max_split) want = max_split;
+  if (want > 8) want = (want + 7) / 8 * 8;
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  const int64_t upb = (units + want - 1) / want;
+  s.split_rows = upb * unit_rows;
+  s.nsplit = (int)((n_str + s.split_rows - 1) / s.split_rows);
+  return s;
+}
+
+template <int MODE, int SPW>
+static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
+  dim3 grid((unsigned)(rblks * a.nsplit)), block(256);
+  if (d == 64) hipLaunchKernelGGL((qstream_kernel<64, SPW, MODE>), grid, block, 0, s, a);
+  else if (d == 128) hipLaunchKernelGGL((qstream_kernel<128, SPW, MODE>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((qstream_kernel<256, SPW, MODE>), grid, block, 0, s, a);
+  return 0;
+}
+
+int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
+  switch (mode) {
+    case QM_LSE: return qs_launch_mode<QM_LSE, QS_SPW_FWD>(a, d, rblks, s);
+    case QM_ARGMAX: return qs_launch_mode<QM_ARGMAX, QS_SPW_FWD>(a, d, rblks, s);
+    case QM_TILEMAX: return qs_launch_mode<QM_TILEMAX, QS_SPW_FWD>(a, d, rblks, s);
+    case QM_BWD_DH: return qs_launch_mode<QM_BWD_DH, QS_SPW_BWD>(a, d, rblks, s);
+    case QM_BWD_DE: return qs_launch_mode<QM_BWD_DE, QS_SPW_BWD>(a, d, rblks, s);
+  }
+  return -1;
+}
+
+// =============================================================================================================
+// finalize / reduce kernels
+// =============================================================================================================
+__global__ void qhead_finalize_lse_kernel(const float* __restrict__ pm, const float* __restrict__ pl, int nsplit,
+                                          int64_t rows, float* __restrict__ lse, float* __restrict__ nlse2) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float M = NEG_INF;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pm[(int64_t)s * rows + r]);
+  const float ms = (M == NEG_INF) ? 0.f : M;
+  float L = 0.f;
+  for (int s = 0; s < nsplit; ++s) L += pl[(int64_t)s * rows + r] * fast_exp2((pm[(int64_t)s * rows + r] - ms) * CQL_LOG2E);
+  const float v = ms + logf(L);
+  lse[r] = v;
+  if (nlse2) nlse2[r] = -v * CQL_LOG2E;
+}
+
+__global__ void qhead_finalize_argmax_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int nsplit,
+                                             int64_t rows, float* __restrict__ vmax, int32_t* __restrict__ imax) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float bv = NEG_INF;
+  int bi = 0x7FFFFFFF;
+  for (int s = 0; s < nsplit; ++s) {
+    const float v = pv[(int64_t)s * rows + r];
+    const int i = pi[(int64_t)s * rows + r];
+    if (v > bv || (v == bv && i < bi)) {
+      bv = v;
+      bi = i;
+    }
+  }
+  vmax[r] = bv;
+  if (imax) imax[r] = bi;
+}
+
+// dst[row][f] = scale * sum_split slab[split][row][f]  (+ coef[row] * E_b[act[row]][f] when coef != NULL)
+// cs_dst[row]  = scale * sum_split slab_cs[split][row]                           (when slab_cs != NULL)
+template <int D>
+__global__ __launch_bounds__(256) void qhead_bwd_reduce_kernel(const float* __restrict__ slab,
+                                                               const float* __restrict__ slab_cs, int nsplit,
+                                                               int64_t rows, float scale,
+                                                               const float* __restrict__ coef,
+                                                               const int32_t* __restrict__ act,
+                                                               const uint16_t* __restrict__ E_b,
+                                                               float* __restrict__ dst, float* __restrict__ cs_dst) {
+  constexpr int V = D / 4;  // float4 per row
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * V) return;
+  const int64_t row = idx / V;
+  const int c = (int)(idx % V);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nsplit; ++k) {
+    const float4 t = *reinterpret_cast<const float4*>(slab + ((int64_t)k * rows + row) * D + c * 4);
+    s.x += t.x;
+    s.y += t.y;
+    s.z += t.z;
+    s.w += t.w;
+  }
+  s.x *= scale;
+  s.y *= scale;
+  s.z *= scale;
+  s.w *= scale;
+  if (coef) {
+    const float cf = coef[row];
+    const uint2 e = *reinterpret_cast<const uint2*>(E_b + (int64_t)act[row] * D + c * 4);
+    s.x = fmaf(cf, __uint_as_float(e.x << 16), s.x);
+    s.y = fmaf(cf, __uint_as_float(e.x & 0xFFFF0000u), s.y);
+    s.z = fmaf(cf, __uint_as_float(e.y << 16), s.z);
+    s.w = fmaf(cf, __uint_as_float(e.y & 0xFFFF0000u), s.w);
+  }
+  *reinterpret_cast<float4*>(dst + row * D + c * 4) = s;
+  if (slab_cs && c == 0) {
+    float t = 0.f;
+    for (int k = 0; k < nsplit; ++k) t += slab_cs[(int64_t)k * rows + row];
+    cs_dst[row] = t * scale;
+  }
+}
+
+// sparse one-hot part of dQ:  g_E_out[act[b]] += coef[b] H_b[b];  g_b_out[act[b]] += coef[b]
+template <int D>
+__global__ __launch_bounds__(256) void qhead_bwd_sparse_kernel(const float* __restrict__ coef,
+                                                               const int32_t* __restrict__ act,
+                                                               const uint16_t* __restrict__ H_b, int64_t batch,
+                                                               float* __restrict__ gE, float* __restrict__ gb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= batch) return;
+  const float cf = coef[b];
+  const int64_t j = act[b];
+#pragma unroll
+  for (int k = 0; k < D / 64; ++k)
+    atomicAdd(gE + j * D + k * 64 + lane, cf * bf16_bits_to_f32(H_b[b * D + k * 64 + lane]));
+  if (lane == 0) atomicAdd(gb + j, cf);
+}
+
+// =============================================================================================================
+// C ABI
+// =============================================================================================================
+static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" int64_t cqlrec_qhead_ws_bytes(int64_t rows, int64_t n_items, int32_t d) {
+  (void)d;
+  const QSplit sp = qs_choose_split(n_items, rows, QS_SPW_FWD, QS_TI);
+  return 3 * align256((int64_t)sp.nsplit * rows * 4) + 256;
+}
+
+extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
+                                int64_t n_items, int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val,
+                                int32_t* out_idx, float* out_nlse2, cqlrec_stream stream) {
+  CQL_REQUIRE(H_b && E_out_b && b_out && ws && out_val, "qhead_fwd: NULL pointer");
+  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_fwd: d=%d unsupported", d);
+  CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
+  CQL_REQUIRE(mode == CQLREC_QHEAD_LSE || mode == CQLREC_QHEAD_ARGMAX, "qhead_fwd: bad mode %d", mode);
+  CQL_REQUIRE(ws_bytes >= cqlrec_qhead_ws_bytes(rows, n_items, d), "qhead_fwd: workspace too small");
+  const QSplit sp = qs_choose_split(n_items, rows, QS_SPW_FWD, QS_TI);
+  const int64_t seg = align256((int64_t)sp.nsplit * rows * 4);
+  QArgs a = {};
+  a.res = H_b;
+  a.n_res = rows;
+  a.str = E_out_b;
+  a.n_str = n_items;
+  a.str_scalar = b_out;
+  a.res_scalar = nullptr;
+  a.nsplit = sp.nsplit;
+  a.split_rows = sp.split_rows;
+  a.part_a = (float*)ws;
+  a.part_b = (float*)((char*)ws + seg);
+  a.part_i = (int32_t*)((char*)ws + 2 * seg);
+  a.tg = 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int thr = 256;
+  if (mode == CQLREC_QHEAD_LSE) {
+    qs_launch(QM_LSE, a, d, sp.rblks, s);
+    hipLaunchKernelGGL(qhead_finalize_lse_kernel, dim3(cql_ceil_div(rows, thr)), dim3(thr), 0, s, a.part_a, a.part_b,
+                       a.nsplit, rows, out_val, out_nlse2);
+  } else {
+    qs_launch(QM_ARGMAX, a, d, sp.rblks, s);
+    hipLaunchKernelGGL(qhead_finalize_argmax_kernel, dim3(cql_ceil_div(rows, thr)), dim3(thr), 0, s, a.part_a, a.part_i,
+                       a.nsplit, rows, out_val, out_idx);
+  }
+  CQL_LAUNCH_CHECK("qhead_fwd");
+  return CQLREC_OK;
+}
+
+extern "C" int64_t cqlrec_qhead_bwd_ws_bytes(int64_t batch, int64_t n_items, int32_t d) {
+  const QSplit s1 = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI);
+  const QSplit s2 = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI);
+  const int64_t a1 = align256((int64_t)s1.nsplit * batch * d * 4);
+  const int64_t a2 = align256((int64_t)s2.nsplit * n_items * d * 4) + align256((int64_t)s2.nsplit * n_items * 4);
+  return (a1 > a2 ? a1 : a2) + 256;
+}
+
+extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                                int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
+                                float scale, void* ws, int64_t ws_bytes, float* dH, float* g_E_out, float* g_b_out,
+                                cqlrec_stream stream) {
+  CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && dH && g_E_out && g_b_out, "qhead_bwd: NULL pointer");
+  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_bwd: d=%d unsupported", d);
+  CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
+  CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  // ---- dH: owner = states, streamed = items ----
+  {
+    const QSplit sp = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI);
+    QArgs a = {};
+    a.res = H_b;
+    a.n_res = batch;
+    a.str = E_out_b;
+    a.n_str = n_items;
+    a.str_scalar = b_out;
+    a.res_scalar = nlse2;
+    a.nsplit = sp.nsplit;
+    a.split_rows = sp.split_rows;
+    a.slab = (float*)ws;
+    a.tg = 1;
+    qs_launch(QM_BWD_DH, a, d, sp.rblks, s);
+    const int64_t n4 = batch * (d / 4);
+    dim3 grid(cql_ceil_div(n4, 256)), block(256);
+#define RED_DH(DD)                                                                                                  \
+  hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, (const float*)nullptr, a.nsplit, batch, \
+                     scale, coef, act, E_out_b, dH, (float*)nullptr)
+    if (d == 64) RED_DH(64); else if (d == 128) RED_DH(128); else RED_DH(256);
+#undef RED_DH
+  }
+  // ---- dE_out / db_out: owner = items, streamed = states ----
+  {
+    const QSplit sp = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI);
+    QArgs a = {};
+    a.res = E_out_b;
+    a.n_res = n_items;
+    a.str = H_b;
+    a.n_str = batch;
+    a.str_scalar = nlse2;
+    a.res_scalar = b_out;
+    a.nsplit = sp.nsplit;
+    a.split_rows = sp.split_rows;
+    a.slab = (float*)ws;
+    a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * n_items * d * 4));
+    a.tg = 1;
+    qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
+    const int64_t n4 = n_items * (d / 4);
+    dim3 grid(cql_ceil_div(n4, 256)), block(256);
+#define RED_DE(DD)                                                                                              \
+  hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, a.slab_cs, a.nsplit, n_items, scale, \
+                     (const float*)nullptr, (const int32_t*)nullptr, (const uint16_t*)nullptr, g_E_out, g_b_out)
+    if (d == 64) RED_DE(64); else if (d == 128) RED_DE(128); else RED_DE(256);
+#undef RED_DE
+    dim3 g2(cql_ceil_div(batch, 4));
+#define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
+    if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);
+#undef SP_DE
+  }
+  CQL_LAUNCH_CHECK("qhead_bwd");
+  return CQLREC_OK;
+}

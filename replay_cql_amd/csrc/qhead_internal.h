@@ -1,0 +1,41 @@
+// Internal interface of the streaming Q-head skeleton (shared by qhead.hip and topk.hip).
+#pragma once
+#include "common.h"
+
+#define QM_LSE 1
+#define QM_ARGMAX 2
+#define QM_TILEMAX 3
+#define QM_BWD_DH 4
+#define QM_BWD_DE 5
+
+#define QS_TI 64            // host-side unit of streamed rows (split boundaries are multiples of it)
+#define QS_SPW_FWD 2        // 32-row owner groups per wave, forward modes (64 states per wave, 256 per block)
+#define QS_SPW_BWD 1        // backward modes (32 owners per wave, 128 per block)
+#define QS_TARGET_BLOCKS 768
+
+struct QArgs {
+  const uint16_t* res;       // owner rows   [n_res x D] bf16
+  int64_t n_res;
+  const uint16_t* str;       // streamed rows [n_str x D] bf16
+  int64_t n_str;
+  const float* str_scalar;   // per streamed row: bias (fwd, BWD_DH) / -lse*log2e (BWD_DE)
+  const float* res_scalar;   // per owner row:    -lse*log2e (BWD_DH) / bias (BWD_DE)
+  int nsplit;
+  int64_t split_rows;        // streamed rows per slice (multiple of QS_TI and of 32*tg)
+  float* part_a;             // [nsplit][n_res]  running max
+  float* part_b;             // [nsplit][n_res]  running sum (LSE)
+  int32_t* part_i;           // [nsplit][n_res]  argmax
+  float* tilemax;            // [ngroups][n_res] (TILEMAX)
+  int tg;                    // 32-row tiles per tile group (TILEMAX)
+  float* slab;               // [nsplit][n_res][D] (backward)
+  float* slab_cs;            // [nsplit][n_res]    (BWD_DE column sums of P)
+};
+
+struct QSplit {
+  int nsplit;
+  int64_t split_rows;
+  int64_t rblks;
+};
+
+QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows);
+int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);

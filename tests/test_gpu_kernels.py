@@ -1,0 +1,467 @@
+"""GPU parity tests, kernel by kernel, THROUGH THE C ABI (include/cqlrec.h) against the CPU oracle.
+
+Bars (SURVEY 8.0 P-rules): integer / index work bit-exact; dyadic fixtures bit-exact for Q, max, argmax, top-K;
+random data |dQ| <= 1e-3 (fp32 reductions: 1e-4 relative here); Adam bit-exact given identical gradients."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cql_oracle as O
+from replay_cql_amd import _native as N
+
+from helpers import DEV, bf16_dev, bf16_to_np, dev, ptr, rel_err, small_log, stream, sync, ws_bytes_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return N.load()
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+@pytest.mark.parametrize("seed,step,slot0,batch", [(0, 0, 0, 256), (3, 17, 4096, 1000), (2**40 + 5, 2**33, 12345, 77)])
+def test_sampler_bit_exact(lib, seed, step, slot0, batch):
+    off, items, rew = small_log(U=300, N=500, seed=4, mean_len=20, max_len=60)
+    # users with empty rows in the middle
+    U = len(off) - 1
+    d_off, d_items, d_rew = dev(off), dev(items), dev(rew)
+    outs = [torch.empty(batch, dtype=torch.int32, device=DEV) for _ in range(3)] + \
+           [torch.empty(batch, dtype=torch.float32, device=DEV) for _ in range(2)]
+    N.check(lib.cqlrec_sample_transitions(ptr(d_off), ptr(d_items), ptr(d_rew), U, seed, step, slot0, batch,
+                                          *[ptr(o) for o in outs], stream()))
+    sync()
+    pos = O.sample_positions(seed, step, slot0, batch, int(off[-1]))
+    users, tpos = O.positions_to_transitions(pos, off)
+    assert np.array_equal(outs[0].cpu().numpy(), users)
+    assert np.array_equal(outs[1].cpu().numpy(), tpos)
+    assert np.array_equal(outs[2].cpu().numpy(), items[pos])
+    assert np.array_equal(outs[3].cpu().numpy(), rew[pos])
+    cnt = off[users.astype(np.int64) + 1] - off[users]
+    assert np.array_equal(outs[4].cpu().numpy(), (tpos == cnt - 1).astype(np.float32))
+
+
+def test_sampler_empty_users(lib):
+    off = np.array([0, 0, 3, 3, 3, 7, 7], dtype=np.int64)
+    items = np.arange(7, dtype=np.int32)
+    rew = np.linspace(0, 1, 7).astype(np.float32)
+    batch = 512
+    outs = [torch.empty(batch, dtype=torch.int32, device=DEV) for _ in range(3)] + \
+           [torch.empty(batch, dtype=torch.float32, device=DEV) for _ in range(2)]
+    N.check(lib.cqlrec_sample_transitions(ptr(dev(off)), ptr(dev(items)), ptr(dev(rew)), 6, 9, 1, 0, batch,
+                                          *[ptr(o) for o in outs], stream()))
+    sync()
+    pos = O.sample_positions(9, 1, 0, batch, 7)
+    users, tpos = O.positions_to_transitions(pos, off)
+    assert set(np.unique(users)) <= {1, 4}
+    assert np.array_equal(outs[0].cpu().numpy(), users) and np.array_equal(outs[1].cpu().numpy(), tpos)
+
+
+# ------------------------------------------------------------------------------------------------ gather
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("dyadic", [True, False])
+def test_gather_pool_fwd(lib, d, dyadic):
+    Nn, L = 301, 7
+    off, items, _ = small_log(U=80, N=Nn, seed=2, mean_len=10, max_len=30)
+    m = O.OracleModel.create(Nn, d, seed=5, dyadic=dyadic)
+    E_in_b = O.bf16_round(m.layout.view(m.theta, "E_in"))
+    rng = np.random.default_rng(0)
+    users = rng.integers(0, 80, 333).astype(np.int32)
+    cnt = (off[users.astype(np.int64) + 1] - off[users]).astype(np.int64)
+    ends = (rng.integers(0, 10**6, 333) % (cnt + 1)).astype(np.int32)  # 0..count (0 -> empty window)
+    ends[:5] = 0
+    h0_ref, len_ref = O.gather_pool(E_in_b, off, items, users, ends, L)
+    h0 = torch.empty((333, d), dtype=torch.float32, device=DEV)
+    h0b = torch.empty((333, d), dtype=torch.bfloat16, device=DEV)
+    lens = torch.empty(333, dtype=torch.int32, device=DEV)
+    N.check(lib.cqlrec_gather_pool_fwd(ptr(bf16_dev(E_in_b)), ptr(dev(off)), ptr(dev(items)), ptr(dev(users)),
+                                       ptr(dev(ends)), 0, 333, L, d, ptr(h0), ptr(h0b), ptr(lens), stream()))
+    sync()
+    assert np.array_equal(lens.cpu().numpy(), len_ref)
+    if dyadic:
+        # sums of <= 7 multiples of 2^-6 are exact; the division is one correctly rounded fp32 op on both sides
+        assert np.array_equal(h0.cpu().numpy(), h0_ref)
+    else:
+        np.testing.assert_allclose(h0.cpu().numpy(), h0_ref, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(bf16_to_np(h0b), O.bf16_round(h0.cpu().numpy()))
+    # predict-time state: ends == NULL -> whole history
+    h0p = torch.empty((333, d), dtype=torch.float32, device=DEV)
+    N.check(lib.cqlrec_gather_pool_fwd(ptr(bf16_dev(E_in_b)), ptr(dev(off)), ptr(dev(items)), ptr(dev(users)), None,
+                                       0, 333, L, d, ptr(h0p), None, None, stream()))
+    sync()
+    ref_p, _ = O.gather_pool(E_in_b, off, items, users, cnt, L)
+    np.testing.assert_allclose(h0p.cpu().numpy(), ref_p, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_gather_pool_bwd(lib, d):
+    Nn, L, n = 97, 6, 200
+    off, items, _ = small_log(U=50, N=Nn, seed=3, mean_len=9, max_len=25)
+    rng = np.random.default_rng(1)
+    users = rng.integers(0, 50, n).astype(np.int32)
+    cnt = (off[users.astype(np.int64) + 1] - off[users]).astype(np.int64)
+    ends = (rng.integers(0, 10**6, n) % (cnt + 1)).astype(np.int32)
+    dh0 = (rng.integers(-8, 9, (n, d)) / 4.0).astype(np.float32)   # dyadic: atomic order cannot matter
+    g = torch.zeros(((Nn + 1), d), dtype=torch.float32, device=DEV)
+    N.check(lib.cqlrec_gather_pool_bwd(ptr(dev(dh0)), ptr(dev(off)), ptr(dev(items)), ptr(dev(users)), ptr(dev(ends)),
+                                       0, n, L, d, ptr(g), stream()))
+    sync()
+    ref = np.zeros((Nn + 1, d), dtype=np.float64)
+    for i in range(n):
+        ln = min(int(ends[i]), L)
+        base = int(off[users[i]]) + int(ends[i])
+        for it in items[base - ln: base]:
+            ref[it] += dh0[i].astype(np.float32) / np.float32(ln)
+    np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert np.all(g.cpu().numpy()[Nn] == 0)
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("rows", [1, 45, 256])
+def test_linear_bf16(lib, d, rows):
+    rng = np.random.default_rng(d + rows)
+    for dyadic in (True, False):
+        if dyadic:
+            X = (rng.integers(-8, 9, (rows, d)) / 8.0).astype(np.float32)
+            W = (rng.integers(-8, 9, (d, d)) / 16.0).astype(np.float32)
+            bias = (rng.integers(-8, 9, d) / 8.0).astype(np.float32)
+        else:
+            X = rng.standard_normal((rows, d)).astype(np.float32)
+            W = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)
+            bias = rng.standard_normal(d).astype(np.float32)
+        Xb, Wb = O.bf16_round(X), O.bf16_round(W)
+        for relu in (0, 1):
+            ref = Xb @ Wb.T + bias
+            if relu:
+                ref = np.maximum(ref, 0)
+            Y = torch.empty((rows, d), dtype=torch.float32, device=DEV)
+            Yb = torch.empty((rows, d), dtype=torch.bfloat16, device=DEV)
+            N.check(lib.cqlrec_linear_bf16(ptr(bf16_dev(Xb)), ptr(bf16_dev(Wb)), ptr(dev(bias)), rows, d, relu, ptr(Y),
+                                           ptr(Yb), stream()))
+            sync()
+            if dyadic:
+                assert np.array_equal(Y.cpu().numpy(), ref.astype(np.float32))
+            else:
+                np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+            assert np.array_equal(bf16_to_np(Yb), O.bf16_round(Y.cpu().numpy()))
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("rows", [37, 300])
+def test_encoder_bwd(lib, d, rows):
+    rng = np.random.default_rng(7 * d + rows)
+    dH = rng.standard_normal((rows, d)).astype(np.float32)
+    zb = O.bf16_round(np.maximum(rng.standard_normal((rows, d)), 0).astype(np.float32))
+    h0b = O.bf16_round(rng.standard_normal((rows, d)).astype(np.float32))
+    W1b = O.bf16_round((rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32))
+    W2b = O.bf16_round((rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32))
+    nb = int(lib.cqlrec_encoder_bwd_ws_bytes(rows, d))
+    ws = ws_bytes_tensor(nb)
+    gW1 = torch.empty((d, d), dtype=torch.float32, device=DEV)
+    gW2 = torch.empty_like(gW1)
+    gb1 = torch.empty(d, dtype=torch.float32, device=DEV)
+    gb2 = torch.empty_like(gb1)
+    dh0 = torch.empty((rows, d), dtype=torch.float32, device=DEV)
+    N.check(lib.cqlrec_encoder_bwd(ptr(dev(dH)), ptr(bf16_dev(zb)), ptr(bf16_dev(h0b)), ptr(bf16_dev(W1b)),
+                                   ptr(bf16_dev(W2b)), rows, d, ptr(ws), nb, ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2),
+                                   ptr(dh0), stream()))
+    sync()
+    dH64 = dH.astype(np.float64)
+    dA1 = (dH64 @ W2b) * (zb > 0)
+    assert rel_err(gb2.cpu().numpy(), dH64.sum(0)) < 1e-5
+    assert rel_err(gW2.cpu().numpy(), dH64.T @ zb) < 1e-5
+    assert rel_err(gb1.cpu().numpy(), dA1.sum(0)) < 1e-5
+    assert rel_err(gW1.cpu().numpy(), dA1.T @ h0b) < 1e-5
+    assert rel_err(dh0.cpu().numpy(), dA1 @ W1b) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ Q-head forward
+def _qhead_inputs(rows, Nn, d, dyadic, seed):
+    rng = np.random.default_rng(seed)
+    if dyadic:
+        H = (rng.integers(-8, 9, (rows, d)) / 8.0).astype(np.float32)
+        E = (rng.integers(-8, 9, (Nn, d)) / 8.0).astype(np.float32)
+        b = (rng.integers(-16, 17, Nn) / 8.0).astype(np.float32)
+    else:
+        H = rng.standard_normal((rows, d)).astype(np.float32)
+        E = (rng.standard_normal((Nn, d)) / np.sqrt(d)).astype(np.float32)
+        b = (rng.standard_normal(Nn) * 0.3).astype(np.float32)
+    return O.bf16_round(H), O.bf16_round(E), b
+
+
+QSHAPES = [(1, 5, 64), (33, 257, 64), (100, 1000, 128), (257, 4099, 128), (70, 513, 256), (512, 10007, 64)]
+
+
+@pytest.mark.parametrize("rows,Nn,d", QSHAPES)
+@pytest.mark.parametrize("dyadic", [True, False])
+def test_qhead_fwd(lib, rows, Nn, d, dyadic):
+    Hb, Eb, b = _qhead_inputs(rows, Nn, d, dyadic, rows * 31 + Nn)
+    Q = O.qvalues(Hb, Eb, b)
+    nb = int(lib.cqlrec_qhead_ws_bytes(rows, Nn, d))
+    ws = ws_bytes_tensor(nb)
+    dH, dE, db = bf16_dev(Hb), bf16_dev(Eb), dev(b)
+    lse = torch.empty(rows, dtype=torch.float32, device=DEV)
+    nlse2 = torch.empty_like(lse)
+    N.check(lib.cqlrec_qhead_fwd(ptr(dH), rows, ptr(dE), ptr(db), Nn, d, N.QHEAD_LSE, ptr(ws), nb, ptr(lse), None,
+                                 ptr(nlse2), stream()))
+    vmax = torch.empty(rows, dtype=torch.float32, device=DEV)
+    imax = torch.empty(rows, dtype=torch.int32, device=DEV)
+    N.check(lib.cqlrec_qhead_fwd(ptr(dH), rows, ptr(dE), ptr(db), Nn, d, N.QHEAD_ARGMAX, ptr(ws), nb, ptr(vmax),
+                                 ptr(imax), None, stream()))
+    sync()
+    Q64 = Q.astype(np.float64)
+    lse_ref = Q64.max(1) + np.log(np.exp(Q64 - Q64.max(1, keepdims=True)).sum(1))
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, rtol=0, atol=1e-4 * max(1.0, np.abs(lse_ref).max()))
+    np.testing.assert_allclose(nlse2.cpu().numpy(), -lse.cpu().numpy() * np.float32(1.4426950408889634), rtol=1e-6)
+    if dyadic:
+        assert np.array_equal(vmax.cpu().numpy(), Q.max(1))            # P2: exact
+        assert np.array_equal(imax.cpu().numpy(), O.argmax_rows(Q))     # ties -> smallest j
+    else:
+        np.testing.assert_allclose(vmax.cpu().numpy(), Q.max(1), atol=1e-3)
+        got = imax.cpu().numpy().astype(np.int64)
+        # the chosen item's oracle Q must be within 1e-4 of the oracle max (P3 margin rule)
+        assert np.all(Q[np.arange(rows), got] >= Q.max(1) - 1e-4)
+
+
+def test_qhead_argmax_ties(lib):
+    """duplicate catalogue rows: the smallest index must win, across tiles, lane halves and slices."""
+    rows, Nn, d = 64, 3000, 64
+    Hb, Eb, b = _qhead_inputs(rows, Nn, d, True, 5)
+    Eb[:] = Eb[0]
+    b[:] = 0.25
+    first = np.random.default_rng(0).integers(0, Nn, 7)
+    nb = int(lib.cqlrec_qhead_ws_bytes(rows, Nn, d))
+    ws = ws_bytes_tensor(nb)
+    vmax = torch.empty(rows, dtype=torch.float32, device=DEV)
+    imax = torch.empty(rows, dtype=torch.int32, device=DEV)
+    for f in [0, 1, 31, 32, 63, 64] + list(first):
+        bb = b.copy()
+        bb[f:] += 1.0   # items f.. all share the maximum -> argmax must be f
+        N.check(lib.cqlrec_qhead_fwd(ptr(bf16_dev(Hb)), rows, ptr(bf16_dev(Eb)), ptr(dev(bb)), Nn, d, N.QHEAD_ARGMAX,
+                                     ptr(ws), nb, ptr(vmax), ptr(imax), None, stream()))
+        sync()
+        assert np.all(imax.cpu().numpy() == f), f
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_gather_dot(lib, d):
+    rows, Nn = 77, 300
+    Hb, Eb, b = _qhead_inputs(rows, Nn, d, True, d)
+    idx = np.random.default_rng(3).integers(0, Nn, rows).astype(np.int32)
+    out = torch.empty(rows, dtype=torch.float32, device=DEV)
+    N.check(lib.cqlrec_gather_dot(ptr(bf16_dev(Hb)), ptr(bf16_dev(Eb)), ptr(dev(b)), ptr(dev(idx)), rows, d, ptr(out),
+                                  stream()))
+    sync()
+    ref = np.einsum("rd,rd->r", Hb, Eb[idx]) + b[idx]
+    assert np.array_equal(out.cpu().numpy(), ref.astype(np.float32))
+
+
+def test_td_loss(lib):
+    B = 1000
+    rng = np.random.default_rng(2)
+    q_a, lse, qt, rew = [rng.standard_normal(B).astype(np.float32) for _ in range(4)]
+    lse = lse + 5
+    done = (rng.random(B) < 0.2).astype(np.float32)
+    coef = torch.empty(B, dtype=torch.float32, device=DEV)
+    y = torch.empty_like(coef)
+    loss = torch.empty(1, dtype=torch.float32, device=DEV)
+    gamma, alpha, inv = 0.99, 0.7, 1.0 / (2 * B)
+    N.check(lib.cqlrec_td_loss(ptr(dev(q_a)), ptr(dev(lse)), ptr(dev(qt)), ptr(dev(rew)), ptr(dev(done)), B, gamma, alpha,
+                               inv, ptr(coef), ptr(y), ptr(loss), stream()))
+    sync()
+    y_ref = rew + np.float32(gamma) * (1 - done) * qt
+    delta = q_a - y_ref
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(coef.cpu().numpy(), (delta - alpha) * inv, rtol=1e-5, atol=1e-9)
+    ref = (0.5 * delta.astype(np.float64) ** 2 + alpha * (lse - q_a)).sum() * inv
+    assert abs(loss.item() - ref) < 1e-5 * abs(ref)
+
+
+# ------------------------------------------------------------------------------------------------ Q-head backward
+@pytest.mark.parametrize("B,Nn,d", [(32, 64, 64), (50, 257, 64), (128, 1000, 128), (300, 4099, 128), (96, 513, 256),
+                                    (1024, 10007, 64)])
+def test_qhead_bwd(lib, B, Nn, d):
+    Hb, Eb, b = _qhead_inputs(B, Nn, d, False, B + Nn)
+    Hb = O.bf16_round(Hb * 0.5)
+    rng = np.random.default_rng(B)
+    act = rng.integers(0, Nn, B).astype(np.int32)
+    act[: min(B, 8)] = act[0]                     # duplicate actions -> atomics on the same row
+    coef = (rng.standard_normal(B) * 0.01).astype(np.float32)
+    scale = np.float32(1.0 / B)
+    Q = O.qvalues(Hb, Eb, b)
+    lse = O.logsumexp_rows(Q)
+    P = np.exp(Q - lse[:, None]).astype(np.float32)
+    Pb = O.bf16_round(P).astype(np.float64)
+    dH_ref = scale * (Pb @ Eb) + coef[:, None] * Eb[act]
+    gE_ref = scale * (Pb.T @ Hb)
+    np.add.at(gE_ref, act, coef[:, None].astype(np.float64) * Hb)
+    gb_ref = scale * P.astype(np.float64).sum(0)
+    np.add.at(gb_ref, act, coef)
+    nlse2 = (-lse * np.float32(1.4426950408889634)).astype(np.float32)
+
+    nb = int(lib.cqlrec_qhead_bwd_ws_bytes(B, Nn, d))
+    ws = ws_bytes_tensor(nb)
+    dH = torch.empty((B, d), dtype=torch.float32, device=DEV)
+    gE = torch.full((Nn, d), 7.0, dtype=torch.float32, device=DEV)     # must be overwritten
+    gb = torch.full((Nn,), 7.0, dtype=torch.float32, device=DEV)
+    N.check(lib.cqlrec_qhead_bwd(ptr(bf16_dev(Hb)), ptr(dev(nlse2)), ptr(dev(coef)), ptr(dev(act)), B, ptr(bf16_dev(Eb)),
+                                 ptr(dev(b)), Nn, d, float(scale), ptr(ws), nb, ptr(dH), ptr(gE), ptr(gb), stream()))
+    sync()
+    # bf16(P) may differ from the oracle's by one bf16 ulp on a few elements (exp2 vs exp): 2e-3 normwise
+    assert rel_err(dH.cpu().numpy(), dH_ref) < 2e-3
+    assert rel_err(gE.cpu().numpy(), gE_ref) < 2e-3
+    assert rel_err(gb.cpu().numpy(), gb_ref) < 1e-4
+    # elementwise, scaled by the largest entry
+    assert np.abs(dH.cpu().numpy() - dH_ref).max() < 3e-3 * np.abs(dH_ref).max()
+    assert np.abs(gE.cpu().numpy() - gE_ref).max() < 3e-3 * np.abs(gE_ref).max()
+
+
+# ------------------------------------------------------------------------------------------------ Adam
+def test_adam_bit_exact(lib):
+    n = 64 * 1000
+    rng = np.random.default_rng(11)
+    theta = rng.standard_normal(n).astype(np.float32)
+    target = (theta + rng.standard_normal(n).astype(np.float32) * 0.01).astype(np.float32)
+    m = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    v = (rng.random(n) * 1e-4).astype(np.float32)
+    g = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    g[:100] = 0
+    v[:50] = 0
+    m[:50] = 0
+    d_th, d_g, d_m, d_v, d_t = dev(theta), dev(g), dev(m), dev(v), dev(target)
+    d_thb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    d_tb = torch.empty_like(d_thb)
+    for t in (1, 2, 1000):
+        step_size, sqrt_bc2 = O.adam_scalars(t, 1e-3, 0.9, 0.999)
+        N.check(lib.cqlrec_adam_ema(ptr(d_th), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_t), ptr(d_thb), ptr(d_tb), n,
+                                    float(step_size), float(sqrt_bc2), 0.9, 0.999, 1e-8, 0.005, 0, stream()))
+        sync()
+        with np.errstate(all="ignore"):
+            O.adam_ema_step(theta, g, m, v, target, t, 1e-3)
+        assert np.array_equal(d_th.cpu().numpy(), theta)
+        assert np.array_equal(d_m.cpu().numpy(), m)
+        assert np.array_equal(d_v.cpu().numpy(), v)
+        assert np.array_equal(d_t.cpu().numpy(), target)
+        assert np.array_equal(bf16_to_np(d_thb), O.bf16_round(theta))
+        assert np.array_equal(bf16_to_np(d_tb), O.bf16_round(target))
+    N.check(lib.cqlrec_adam_ema(ptr(d_th), ptr(d_g), ptr(d_m), ptr(d_v), ptr(d_t), ptr(d_thb), ptr(d_tb), n, 1e-3, 1.0,
+                                0.9, 0.999, 1e-8, 0.005, 1, stream()))
+    sync()
+    assert torch.count_nonzero(d_g).item() == 0
+
+
+# ------------------------------------------------------------------------------------------------ top-K
+def _topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None):
+    Hb, Eb, b = _qhead_inputs(n_users, Nn, d, dyadic, seed)
+    rng = np.random.default_rng(seed)
+    ids = np.arange(Nn, dtype=np.int32) if cand is None else cand
+    E_c, b_c = Eb[ids], b[ids]
+    Q = O.qvalues(Hb, E_c, b_c)
+    seen_off = seen_items = None
+    if with_seen:
+        cnts = rng.integers(0, 40, n_users)
+        cnts[0] = 0
+        seen_off = np.zeros(n_users + 1, dtype=np.int64)
+        np.cumsum(cnts, out=seen_off[1:])
+        rows = []
+        for u in range(n_users):
+            top = np.argsort(-Q[u])[: cnts[u] // 2]                   # half of the seen items are the best ones
+            rnd = rng.integers(0, Nn, cnts[u] - len(top))
+            row = np.unique(np.concatenate([ids[top], rnd]).astype(np.int32))
+            rows.append(row)
+            seen_off[u + 1] = seen_off[u] + len(row)
+        seen_items = np.concatenate(rows).astype(np.int32) if rows else np.zeros(0, np.int32)
+        pos_of = -np.ones(Nn, dtype=np.int64)
+        pos_of[ids] = np.arange(len(ids))
+        for u in range(n_users):
+            p = pos_of[seen_items[seen_off[u]: seen_off[u + 1]]]
+            Q[u, p[p >= 0]] = -np.inf
+    kk = min(k, len(ids))
+    idx_c, val_ref = O.topk_rows(Q, kk)
+    idx_ref = np.where(np.isfinite(val_ref), ids[idx_c], -1)
+
+    nb = int(lib.cqlrec_topk_ws_bytes(n_users, len(ids), d, k))
+    ws = ws_bytes_tensor(nb)
+    out_idx = torch.empty((n_users, k), dtype=torch.int32, device=DEV)
+    out_val = torch.empty((n_users, k), dtype=torch.float32, device=DEV)
+    out_cnt = torch.empty(n_users, dtype=torch.int32, device=DEV)
+    d_ids = None if cand is None else dev(ids)
+    d_so = None if seen_off is None else dev(seen_off)
+    d_si = None if seen_items is None else dev(np.concatenate([seen_items, np.zeros(1, np.int32)]))
+    N.check(lib.cqlrec_score_topk(ptr(bf16_dev(Hb)), n_users, ptr(bf16_dev(E_c)), ptr(dev(b_c)), len(ids), d, ptr(d_ids),
+                                  ptr(d_so), ptr(d_si), None, k, ptr(ws), nb, ptr(out_idx), ptr(out_val), ptr(out_cnt),
+                                  stream()))
+    sync()
+    return out_idx.cpu().numpy(), out_val.cpu().numpy(), out_cnt.cpu().numpy(), idx_ref, val_ref, Q
+
+
+@pytest.mark.parametrize("n_users,Nn,d,k", [(5, 40, 64, 10), (70, 1000, 128, 10), (130, 4099, 64, 25),
+                                            (33, 10007, 128, 100), (20, 513, 256, 7)])
+@pytest.mark.parametrize("with_seen", [False, True])
+def test_topk_dyadic_bit_exact(lib, n_users, Nn, d, k, with_seen):
+    idx, val, cnt, idx_ref, val_ref, _ = _topk_case(lib, n_users, Nn, d, k, True, Nn + k, with_seen)
+    kk = idx_ref.shape[1]
+    valid = np.isfinite(val_ref)
+    assert np.array_equal(cnt, valid.sum(1))
+    assert np.array_equal(np.where(valid, idx[:, :kk], -1), idx_ref)      # P2: sets AND order bit-identical
+    assert np.array_equal(np.where(valid, val[:, :kk], 0), np.where(valid, val_ref, 0))
+    assert np.all(idx[:, kk:] == -1)
+
+
+@pytest.mark.parametrize("with_seen", [False, True])
+def test_topk_random_margin_rule(lib, with_seen):
+    n_users, Nn, d, k = 200, 10007, 128, 10
+    idx, val, cnt, idx_ref, val_ref, Q = _topk_case(lib, n_users, Nn, d, k, False, 99, with_seen)
+    assert np.all(cnt == k)
+    excluded = 0
+    for u in range(n_users):
+        kth = val_ref[u, -1]
+        got, ref = set(idx[u]), set(idx_ref[u])
+        for j in got ^ ref:                       # P3: only boundary items within 1e-4 of the k-th score may differ
+            assert abs(Q[u, j] - kth) < 1e-4
+            excluded += 1
+        np.testing.assert_allclose(val[u], Q[u, idx[u]], atol=1e-3)
+        assert np.all(np.diff(val[u]) <= 0)
+    assert excluded <= 4
+
+
+def test_topk_candidate_subset_and_short_lists(lib):
+    Nn = 3000
+    cand = np.sort(np.random.default_rng(1).choice(Nn, 37, replace=False)).astype(np.int32)
+    idx, val, cnt, idx_ref, val_ref, _ = _topk_case(lib, 16, Nn, 64, 50, True, 8, True, cand=cand)
+    kk = idx_ref.shape[1]
+    valid = np.isfinite(val_ref)
+    assert np.array_equal(cnt, valid.sum(1))          # fewer than k admissible items -> padded
+    assert np.array_equal(np.where(valid, idx[:, :kk], -1), idx_ref)
+    assert np.all(idx[:, kk:] == -1) and np.all(np.isneginf(val[:, kk:]))
+
+
+def test_topk_all_equal_scores(lib):
+    """cold start: every score equal -> items 0..k-1 in order (tie rule)."""
+    n_users, Nn, d, k = 9, 5000, 64, 12
+    Hb = np.zeros((n_users, d), np.float32)
+    Eb = np.zeros((Nn, d), np.float32)
+    b = np.zeros(Nn, np.float32)
+    nb = int(lib.cqlrec_topk_ws_bytes(n_users, Nn, d, k))
+    ws = ws_bytes_tensor(nb)
+    out_idx = torch.empty((n_users, k), dtype=torch.int32, device=DEV)
+    out_val = torch.empty((n_users, k), dtype=torch.float32, device=DEV)
+    out_cnt = torch.empty(n_users, dtype=torch.int32, device=DEV)
+    N.check(lib.cqlrec_score_topk(ptr(bf16_dev(Hb)), n_users, ptr(bf16_dev(Eb)), ptr(dev(b)), Nn, d, None, None, None,
+                                  None, k, ptr(ws), nb, ptr(out_idx), ptr(out_val), ptr(out_cnt), stream()))
+    sync()
+    assert np.array_equal(out_idx.cpu().numpy(), np.tile(np.arange(k, dtype=np.int32), (n_users, 1)))
+
+
+def test_bad_arguments_raise(lib):
+    with pytest.raises(N.CqlrecError, match="unsupported"):
+        N.make_layout(100, 48)
+    with pytest.raises(N.CqlrecError, match="NULL"):
+        N.check(lib.cqlrec_gather_dot(None, None, None, None, 4, 64, None, stream()))
+    with pytest.raises(N.CqlrecError, match="k=0"):
+        t = ws_bytes_tensor(1 << 20)
+        N.check(lib.cqlrec_score_topk(ptr(t), 1, ptr(t), ptr(t), 10, 64, None, None, None, None, 0, ptr(t), 1 << 20,
+                                      ptr(t), ptr(t), ptr(t), stream()))

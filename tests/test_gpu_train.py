@@ -1,0 +1,130 @@
+"""End-to-end GPU parity of the training step and of CQLCore against the oracle (P4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cql_oracle as O
+from replay_cql_amd.core import CQLCore, CQLHyper
+
+from helpers import DEV, bf16_to_np, rel_err, small_log
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(U, Nn, d, B, L, dyadic=False, seed=3, alpha=1.0):
+    off, items, rew = small_log(U=U, N=Nn, seed=seed, mean_len=14, max_len=45)
+    m = O.OracleModel.create(Nn, d, seed=7, dyadic=dyadic)
+    rng = np.random.default_rng(5)
+    if not dyadic:
+        for nm in ("b_out", "b1", "b2"):
+            m.layout.view(m.theta, nm)[:] = (rng.standard_normal(m.layout.shape(nm)) * 0.05).astype(np.float32)
+        m.target[:] = m.theta + (rng.standard_normal(m.theta.shape) * 0.01).astype(np.float32) * (m.theta != 0)
+    hyper = CQLHyper(d=d, window=L, batch=B, seed=11, alpha=alpha)
+    core = CQLCore(Nn, hyper, device=DEV)
+    core.load_flat(m.theta, m.target)
+    core.set_log(off, items, rew)
+    return m, core, (off, items, rew)
+
+
+@pytest.mark.parametrize("U,Nn,d,B,L", [(64, 257, 64, 64, 5), (300, 1000, 128, 256, 8), (200, 4099, 128, 96, 50),
+                                        (100, 513, 256, 128, 10)])
+def test_step_intermediates_and_grads(U, Nn, d, B, L):
+    m, core, (off, items, rew) = _make(U, Nn, d, B, L)
+    lay = m.layout
+    assert int(core.layout.total) == lay.total
+    for nm in ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2"):
+        assert core.layout.offset(nm) == lay.off[nm]
+    loss = torch.zeros(1, device=DEV)
+    core.forward_backward(loss)
+    v = core.views()
+    pos = O.sample_positions(11, 0, 0, B, int(off[-1]))
+    users, tpos = O.positions_to_transitions(pos, off)
+    out = O.loss_and_grads(lay, m.theta, m.target, off, items, rew, users, tpos, L, 0.99, 1.0)
+    assert np.array_equal(v["users"].cpu().numpy(), users) and np.array_equal(v["tpos"].cpu().numpy(), tpos)
+    np.testing.assert_allclose(v["h0_s"].cpu().numpy(), out.h0_s, rtol=1e-5, atol=1e-6)
+    # bf16 state vectors: identical up to one bf16 ulp on rare rounding ties of an fp32 sum
+    for name, ref in (("hb_s", out.hb_s), ("hb_sn", out.hb_sn)):
+        got = bf16_to_np(v[name])
+        assert np.mean(got != ref) < 2e-3
+        np.testing.assert_allclose(got, ref, rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(v["q_a"].cpu().numpy(), out.q_a, atol=1e-3)          # P3 |dQ| <= 1e-3
+    np.testing.assert_allclose(v["lse"].cpu().numpy(), out.lse, atol=1e-3)
+    np.testing.assert_allclose(v["q_targ"].cpu().numpy(), out.q_targ, atol=1e-3)
+    np.testing.assert_allclose(v["y"].cpu().numpy(), out.y, atol=1e-3)
+    assert np.mean(v["a_star"].cpu().numpy() == out.a_star) > 0.98
+    assert abs(loss.item() - out.loss) < 1e-3 * abs(out.loss)
+    assert rel_err(v["dH"].cpu().numpy(), out.dH) < 5e-3
+    assert rel_err(v["dh0"].cpu().numpy(), out.dh0) < 5e-3
+    g = core.grads.cpu().numpy()
+    for nm in ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2"):
+        assert rel_err(lay.view(g, nm), lay.view(out.grads, nm)) < 5e-3, nm
+    # padding and the PAD row never receive gradient
+    mask = np.ones(lay.total, bool)
+    for nm in ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2"):
+        mask[lay.off[nm]: lay.off[nm] + int(np.prod(lay.shape(nm)))] = False
+    assert np.all(g[mask] == 0) and np.all(lay.view(g, "E_in")[Nn] == 0)
+
+
+def test_dyadic_forward_bit_exact():
+    """P2: on dyadic parameters the whole forward (h0, h, Q-values, argmax) is exact."""
+    m, core, (off, items, rew) = _make(80, 513, 64, 64, 4, dyadic=True)
+    core.forward_backward(None)
+    v = core.views()
+    pos = O.sample_positions(11, 0, 0, 64, int(off[-1]))
+    users, tpos = O.positions_to_transitions(pos, off)
+    out = O.loss_and_grads(m.layout, m.theta, m.target, off, items, rew, users, tpos, 4, 0.99, 1.0)
+    assert np.array_equal(v["h0_s"].cpu().numpy(), out.h0_s)
+    assert np.array_equal(bf16_to_np(v["hb_s"]), out.hb_s)
+    assert np.array_equal(bf16_to_np(v["hb_sn"]), out.hb_sn)
+    assert np.array_equal(v["q_a"].cpu().numpy(), out.q_a)
+    assert np.array_equal(v["a_star"].cpu().numpy(), out.a_star)
+    assert np.array_equal(v["q_targ"].cpu().numpy(), out.q_targ)
+
+
+@pytest.mark.parametrize("U,Nn,d,B,L,steps", [(300, 1000, 128, 256, 8, 6), (64, 257, 64, 64, 5, 10)])
+def test_training_trajectory(U, Nn, d, B, L, steps):
+    """P4: loss after n Adam steps within 1e-3 relative; parameters normwise within 1e-3."""
+    m, core, (off, items, rew) = _make(U, Nn, d, B, L)
+    losses = core.train(steps).cpu().numpy()
+    ref = O.train_steps(m, off, items, rew, steps, B, L, seed=11)
+    np.testing.assert_allclose(losses, ref, rtol=1e-3)
+    assert core.step == steps
+    th = core.theta.cpu().numpy()
+    assert rel_err(th, m.theta) < 1e-3
+    assert rel_err(core.target.cpu().numpy(), m.target) < 1e-3
+    # update direction itself (theta moved by ~steps*lr): compare the displacement normwise
+    m0 = O.OracleModel.create(Nn, d, seed=7)
+    assert np.count_nonzero(core.grads.cpu().numpy()) == 0          # re-zeroed by the fused update
+    assert np.array_equal(bf16_to_np(core.theta_b), O.bf16_round(th))
+
+
+def test_core_predict_matches_oracle():
+    U, Nn, d, L, k = 150, 2000, 128, 10, 10
+    m, core, (off, items, rew) = _make(U, Nn, d, 128, L)
+    users = np.arange(U, dtype=np.int32)
+    d_off, d_items = core._csr[0], core._csr[1]
+    hb = core.encode(d_off, d_items, torch.as_tensor(users).to(DEV))
+    # seen CSR = items sorted inside each user's row (same offsets)
+    seen = items.copy()
+    for u in range(U):
+        seen[off[u]: off[u + 1]] = np.sort(seen[off[u]: off[u + 1]])
+    d_seen = torch.as_tensor(seen).to(DEV)
+    idx, val, cnt = core.score_topk(hb, k, seen=(d_off, d_seen), chunk=64)
+    ridx, rval, rcnt, rhb = O.predict_topk(m.layout, m.theta, off, items, users, k, L, filter_seen=True)
+    got_hb = bf16_to_np(hb)
+    assert np.mean(got_hb != rhb) < 2e-3
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
+    Q = O.qvalues(rhb, O.bf16_round(m.layout.view(m.theta, "E_out")), m.layout.view(m.theta, "b_out"))
+    bad = 0
+    for u in range(U):
+        assert not set(idx[u]) & set(items[off[u]: off[u + 1]])      # nothing seen is recommended
+        for j in set(idx[u]) ^ set(ridx[u]):
+            assert abs(Q[u, j] - rval[u, -1]) < 2e-3
+            bad += 1
+        np.testing.assert_allclose(val[u], Q[u, idx[u]], atol=2e-3)
+    assert bad <= 6
+    # pairs
+    pi = np.random.default_rng(0).integers(0, Nn, U).astype(np.int32)
+    ps = core.pair_scores(hb, torch.as_tensor(pi).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(ps, Q[np.arange(U), pi], atol=2e-3)
