@@ -1,0 +1,95 @@
+"""Host-side data plumbing of the hot path: LOG_SCHEMA rows -> CSR by user (S2), seen lists, synthetic logs.
+
+Mirrors what `NeuroMF._fit` does with `log.toPandas()` + DataLoader construction (replay/models/neuromf.py:325-339);
+the arithmetic of training never happens here."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def build_csr(user_idx, item_idx, timestamp, relevance, n_users: Optional[int] = None):
+    """Sort by (user, timestamp asc, item_idx asc) -> offsets int64[U+1], items int32[nnz], rewards float32[nnz]."""
+    user_idx = np.asarray(user_idx, dtype=np.int64)
+    item_idx = np.asarray(item_idx, dtype=np.int64)
+    timestamp = np.asarray(timestamp)
+    if timestamp.dtype.kind == "M":
+        timestamp = timestamp.astype("datetime64[ns]").astype(np.int64)
+    elif timestamp.dtype.kind not in "iuf":
+        timestamp = timestamp.astype("datetime64[ns]").astype(np.int64)
+    relevance = np.asarray(relevance, dtype=np.float64)
+    if not (len(user_idx) == len(item_idx) == len(timestamp) == len(relevance)):
+        raise ValueError("log columns differ in length")
+    if len(user_idx) and (user_idx.min() < 0 or item_idx.min() < 0):
+        raise ValueError("user_idx / item_idx must be non-negative dense indices")
+    if n_users is None:
+        n_users = int(user_idx.max()) + 1 if len(user_idx) else 0
+    order = np.lexsort((item_idx, timestamp, user_idx))
+    counts = np.bincount(user_idx, minlength=n_users).astype(np.int64)
+    offsets = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    return offsets, item_idx[order].astype(np.int32), relevance[order].astype(np.float32)
+
+
+def sorted_seen(offsets: np.ndarray, items: np.ndarray) -> np.ndarray:
+    """Items sorted ascending inside every CSR row (same offsets): the `seen` lists of cqlrec_score_topk."""
+    rows = np.repeat(np.arange(len(offsets) - 1, dtype=np.int64), np.diff(offsets))
+    order = np.lexsort((items, rows))
+    return items[order].astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# synthetic logs on device: a deterministic function of (seed, user, position) so that any user
+# shard is generated identically at any world size.  Benchmark input plumbing, not part of the hot path.
+# ----------------------------------------------------------------------------------------------------------
+_M1, _M2, _GOLD = -0x40A7B892E31B1A47, -0x6B2FB644ECCEEE15, -0x61C8864680B583EB  # splitmix64 constants as int64
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix64(z: torch.Tensor) -> torch.Tensor:
+    z = z + _GOLD
+    z = (z ^ _lsr(z, 30)) * _M1
+    z = (z ^ _lsr(z, 27)) * _M2
+    return z ^ _lsr(z, 31)
+
+
+def _u01(h: torch.Tensor) -> torch.Tensor:
+    return (_lsr(h, 11).to(torch.float64) + 0.5) * (1.0 / (1 << 53))
+
+
+def synth_log_device(n_users: int, n_items: int, seed: int = 12345, device="cuda", user_lo: int = 0,
+                     user_hi: Optional[int] = None, mean_len: float = 40.0, sigma: float = 0.6, min_len: int = 5,
+                     max_len: int = 200, zipf: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """CSR (offsets, items, rewards) of users [user_lo, user_hi) generated on `device`.
+
+    len_u = clip(round(lognormal(ln mean_len, sigma)), min_len, max_len); item ~ Zipf(1) through a fixed affine
+    permutation (uniform if zipf=False); reward in {0.2,...,1.0}; timestamp = position (rows are already ordered)."""
+    user_hi = n_users if user_hi is None else user_hi
+    dev = torch.device(device)
+    u = torch.arange(user_lo, user_hi, dtype=torch.int64, device=dev)
+    hu = _mix64(u ^ (seed * 0x2545F491))
+    # Box-Muller for the log-normal length
+    n1 = torch.sqrt(-2.0 * torch.log(_u01(hu))) * torch.cos(2.0 * math.pi * _u01(_mix64(hu)))
+    lens = torch.clamp(torch.round(torch.exp(math.log(mean_len) + sigma * n1)), min_len, max_len).to(torch.int64)
+    offsets = torch.zeros(user_hi - user_lo + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=offsets[1:])
+    nnz = int(offsets[-1])
+    row = torch.repeat_interleave(torch.arange(user_hi - user_lo, device=dev), lens)
+    pos = torch.arange(nnz, dtype=torch.int64, device=dev) - offsets[row]
+    hp = _mix64(hu[row] + pos * 0x9E3779B1)
+    if zipf:
+        r = torch.floor(torch.exp(_u01(hp) * math.log(n_items + 1.0))).to(torch.int64).clamp_(1, n_items) - 1
+    else:
+        r = (_lsr(hp, 1) % n_items)
+    mult = 2654435761 % n_items
+    while math.gcd(mult, n_items) != 1:
+        mult += 1
+    items = ((r * mult + 12345) % n_items).to(torch.int32)
+    rewards = ((_lsr(_mix64(hp), 3) % 5 + 1).to(torch.float32)) * 0.2
+    return offsets, items.contiguous(), rewards.contiguous()

@@ -25,3 +25,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_buffers():
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        from helpers import release_kept
+        release_kept()
+    except ImportError:
+        pass

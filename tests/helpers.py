@@ -8,19 +8,29 @@ from oracle import cql_oracle as O
 from replay_cql_amd import _native as N
 
 DEV = "cuda:0"
+_KEEP = []   # device tensors handed to the C ABI as raw pointers must outlive the (asynchronous) call
+
+
+def keep(t):
+    _KEEP.append(t)
+    return t
+
+
+def release_kept():
+    _KEEP.clear()
 
 
 def dev(x, dtype=None):
     t = torch.as_tensor(np.ascontiguousarray(x))
     if dtype is not None:
         t = t.to(dtype)
-    return t.to(DEV).contiguous()
+    return keep(t.to(DEV).contiguous())
 
 
 def bf16_dev(x_f32: np.ndarray) -> torch.Tensor:
     """fp32 numpy (any values) -> device bf16 tensor holding oracle-rounded values."""
     bits = O.bf16_bits(np.asarray(x_f32, dtype=np.float32)).astype(np.int16)
-    return torch.as_tensor(bits).to(DEV).view(torch.bfloat16).contiguous()
+    return keep(torch.as_tensor(bits).to(DEV).view(torch.bfloat16).contiguous())
 
 
 def bf16_to_np(t: torch.Tensor) -> np.ndarray:
