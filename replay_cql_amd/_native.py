@@ -96,6 +96,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be loaded first: it bundles its own libamdhip64, and libcqlrec.so has to bind to that same HIP
+    # runtime instance (one runtime per process -- torch's stream handles and device pointers are only valid there).
+    import torch  # noqa: F401  pylint: disable=import-outside-toplevel,unused-import
     if not _LIB_PATH.exists():
         raise CqlrecError(
             f"{_LIB_PATH} is missing: build it with `python -m replay_cql_amd.build` (hipcc --offload-arch=gfx950). "

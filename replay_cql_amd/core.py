@@ -248,6 +248,8 @@ class CQLCore:
         out_cnt = torch.empty((n,), dtype=torch.int32, device=self.device)
         if n == 0:
             return out_idx, out_val, out_cnt
+        if seen is not None and seen_rows is None:
+            seen_rows = torch.arange(n, dtype=torch.int32, device=self.device)
         chunk = max(1, min(chunk, n))
         ws_bytes = int(self.lib.cqlrec_topk_ws_bytes(chunk, n_cand, h.d, k))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
