@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- CQL hot-path throughput on MI355X (BASELINE.json metric: CQL train-steps/sec + top-K users/sec on a
+1M-user x 100K-item synthetic log).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full CQL training step over one batch of B=4096 transitions per GPU (sample, window gather, encoder,
+full-catalog Q-head LSE + argmax, double-Q TD target, CQL loss, backward, [RCCL gradient all-reduce], Adam + Polyak).
+Weak scaling: per-GPU batch fixed, users sharded by rank, no data-path collective besides the gradient all-reduce.
+`value` = (N * K steps of 4096 transitions) / max-over-ranks time, inputs resident in HBM.  After the timed training
+region the all-users top-K pass (K=10, seen items filtered) is timed on a user block and reported in `topk`.
+
+The oracle (oracle/) is used ONLY for the cpu_baseline leg (rank 0, N=1), never in the measured path."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[2] (the configuration the metric is quoted on) and configs[1]
+    "cfg3": dict(users=1_000_000, items=100_000, d=128, window=50, batch=4096, k=10, topk_users=65_536),
+    "cfg2": dict(users=100_000, items=10_000, d=64, window=50, batch=4096, k=10, topk_users=65_536),
+    "tiny": dict(users=2_000, items=1_000, d=64, window=10, batch=256, k=10, topk_users=2_000),
+}
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-topk", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, off, items, rew, budget_s=12.0):
+    """Oracle (numpy restatement, multi-threaded BLAS) on the host cores: identical algorithm, identical batch."""
+    import numpy as np
+    from oracle import cql_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    m = O.OracleModel.create(cfg["items"], cfg["d"], seed=7)
+    t0, n = time.perf_counter(), 0
+    while n < 4 and (n == 0 or time.perf_counter() - t0 < budget_s):
+        with np.errstate(all="ignore"):
+            O.train_steps(m, off, items, rew, 1, cfg["batch"], cfg["window"], seed=0, fast=True)
+        n += 1
+    dt = time.perf_counter() - t0
+    # top-K on a small user sample
+    nu = min(256, len(off) - 1)
+    t1 = time.perf_counter()
+    O.predict_topk(m.layout, m.theta, off, items, np.arange(nu), cfg["k"], cfg["window"], filter_seen=True, fast=True)
+    dtk = time.perf_counter() - t1
+    return {"value": n / dt, "unit": "train-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} oracle train steps (numpy, B={cfg['batch']}, N={cfg['items']}, d={cfg['d']}) on a "
+                      f"{len(off) - 1}-user shard of the same synthetic log; top-K on {nu} users",
+            "topk_users_per_s": nu / dtk}
+
+
+def main():
+    args = parse()
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from replay_cql_amd import _native as N
+    from replay_cql_amd.core import CQLCore, CQLHyper
+    from replay_cql_amd.data import synth_log_device
+
+    lib = N.load()
+    U, NI, d, L, B, K = cfg["users"], cfg["items"], cfg["d"], cfg["window"], cfg["batch"], cfg["k"]
+    lo, hi = rank * U // world, (rank + 1) * U // world
+    off, items, rew = synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi)
+    core = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg)
+    core.set_log(off, items, rew)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss_buf = torch.zeros(args.warmup + args.steps + 1, device=dev)
+
+    def run(n, base):
+        for i in range(n):
+            core.forward_backward(loss_buf[base + i: base + i + 1])
+            core.allreduce_grads()
+            core.apply_update()
+
+    run(args.warmup, 0)
+    barrier()
+    if not args.no_prof:
+        N.check(lib.cqlrec_prof_enable(1), "prof_enable")
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    phases = N.prof_read() if not args.no_prof else {}
+    N.check(lib.cqlrec_prof_enable(0), "prof_enable")
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = loss_buf[args.warmup: args.warmup + args.steps].cpu().tolist()
+
+    # ---- top-K scoring pass (second half of the metric) --------------------------------------------------------
+    topk = None
+    if not args.no_topk:
+        nu = min(cfg["topk_users"], hi - lo)
+        users = torch.arange(nu, dtype=torch.int32, device=dev)
+        # seen lists = items sorted inside each user's row (input preparation, untimed)
+        rows = torch.repeat_interleave(torch.arange(hi - lo, device=dev), off[1:] - off[:-1])
+        seen_items = items[torch.argsort(rows * NI + items.to(torch.int64))].contiguous()
+        del rows
+        hb = core.encode(off, items, users)
+        core.score_topk(hb[:1024], K, seen=(off, seen_items))      # warm-up
+        barrier()
+        if not args.no_prof:
+            N.check(lib.cqlrec_prof_enable(1), "prof_enable")
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            hb = core.encode(off, items, users)
+            idx, val, cnt = core.score_topk(hb, K, seen=(off, seen_items))
+        barrier()
+        dtk = time.perf_counter() - t1
+        tk_ph = N.prof_read() if not args.no_prof else {}
+        N.check(lib.cqlrec_prof_enable(0), "prof_enable")
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dtk], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtk = float(t.item())
+        topk = {"metric": "top-K users/sec", "value": world * reps * nu / dtk, "unit": "users/s", "k": K,
+                "users_per_rank": nu, "filter_seen": True, "ms_per_pass": 1e3 * dtk / reps}
+        if tk_ph.get("topk_tilemax", (0, 0))[1]:
+            ms = tk_ph["topk_tilemax"][0] / tk_ph["topk_tilemax"][1]
+            launches_per_pass = tk_ph["topk_tilemax"][1] / reps
+            fl = 2.0 * nu * NI * d / launches_per_pass
+            topk["roofline"] = {"kernel": "qstream_kernel<TILEMAX>", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+                                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                                "avg_ms": ms}
+            topk["select_ms_per_pass"] = tk_ph["topk_select"][0] / reps
+
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "CQL train-steps/sec", "value": world * args.steps / dt, "unit": "train-steps/s (B=4096 transitions per step and GPU)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[2]: synthetic {U} users x {NI} items, CQL d={d}, L={L}, "
+                               f"B={B}/GPU, bf16 MFMA + fp32 accumulate" if args.config == "cfg3" else args.config,
+                   "users": U, "items": NI, "d": d, "window": L, "batch_per_gpu": B, "global_batch": B * world,
+                   "parallelism": f"dp{world} (users sharded by rank, RCCL gradient all-reduce)", "k": K},
+        "transitions_per_sec": world * args.steps * B / dt,
+        "loss_first_last": [losses[0], losses[-1]] if losses else None,
+    }
+    if phases:
+        per = {p: {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps} for p, (ms, n) in phases.items() if n}
+        out["kernel_ms_per_step"] = {p: round(v["ms_per_step"], 4) for p, v in per.items()}
+        qk = {p: phases[p][0] / max(phases[p][1], 1) for p in ("qhead_lse", "qhead_argmax", "qhead_bwd_dh", "qhead_bwd_de")}
+        dom = max(qk, key=qk.get)
+        flops = 2.0 * B * NI * d          # algorithmic flops of ONE Q-head GEMM (8*B*N*d per step = 4 GEMMs)
+        ach = flops / (qk[dom] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": f"qstream_kernel<{dom}>", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_ms": qk[dom],
+                           "algorithmic_flops_per_launch": flops}
+        q_ms = sum(qk.values())
+        out["roofline_qhead_step"] = {"flops_per_step": 4 * flops, "ms_per_step": q_ms,
+                                      "achieved": 4 * flops / (q_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                      "frac": 4 * flops / (q_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+        # HBM-bound companions (algorithmic bytes)
+        lens = (off[1:] - off[:-1]).clamp(max=L).float().mean().item()
+        g_bytes = B * (lens * d * 2 + lens * 4) + B * d * 4
+        if phases["gather_fwd"][1]:
+            g_ms = phases["gather_fwd"][0] / phases["gather_fwd"][1]
+            out["roofline_gather"] = {"bound": "hbm", "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                      "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                      "avg_ms": g_ms, "note": "E_in table (25.6 MB) is Infinity-Cache resident"}
+        if phases["adam"][1]:
+            a_ms = phases["adam"][0] / phases["adam"][1]
+            a_bytes = int(core.layout.total) * 44
+            out["roofline_adam"] = {"bound": "hbm", "achieved": a_bytes / (a_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                    "unit": "GB/s", "frac": a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": a_ms}
+    if topk:
+        out["topk"] = topk
+    if world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        n_shard = min(hi - lo, 20_000)
+        o_h = off[: n_shard + 1].cpu().numpy()
+        cb = cpu_baseline(cfg, o_h, items[: int(o_h[-1])].cpu().numpy(), rew[: int(o_h[-1])].cpu().numpy())
+        out["cpu_baseline"] = cb
+        out["gpu_over_cpu"] = out["value"] / cb["value"]
+    print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,21 @@ typedef struct cqlrec_train_views {
 } cqlrec_train_views;
 int cqlrec_train_views_get(const cqlrec_train_ctx* ctx /* [host] */, cqlrec_train_views* out /* [host] */);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py): when enabled, every launcher brackets its kernel with a pair of HIP events on
+ * the stream it launches on; cqlrec_prof_read synchronises those events and returns, per phase, the summed
+ * kernel time in ms and the number of launches, then resets the pool.  Not capturable in a hipGraph; off by
+ * default.  The reference's only harness is time.time() around fit/predict
+ * (experiments/02_models_comparison.ipynb:843-867).
+ * --------------------------------------------------------------------------------------------------------- */
+enum {
+  CQLREC_PH_SAMPLE = 0, CQLREC_PH_GATHER_FWD, CQLREC_PH_ENCODER_FWD, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX,
+  CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE, CQLREC_PH_QHEAD_SMALL, CQLREC_PH_ENCODER_BWD,
+  CQLREC_PH_GATHER_BWD, CQLREC_PH_ADAM, CQLREC_PH_TOPK_TILEMAX, CQLREC_PH_TOPK_SELECT, CQLREC_PH_COUNT
+};
+int cqlrec_prof_enable(int32_t on);
+int cqlrec_prof_read(double* ms_sum /* [host] CQLREC_PH_COUNT */, int64_t* launches /* [host] CQLREC_PH_COUNT */);
+
 #ifdef __cplusplus
 }
 #endif

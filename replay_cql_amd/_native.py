@@ -80,7 +80,20 @@ SIGNATURES = {
     "cqlrec_train_step_fwd_bwd": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
     "cqlrec_train_step_update": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), C.POINTER(TrainViews)]),
+    "cqlrec_prof_enable": (i32, [i32]),
+    "cqlrec_prof_read": (i32, [C.POINTER(C.c_double), C.POINTER(i64)]),
 }
+
+PHASES = ("sample", "gather_fwd", "encoder_fwd", "qhead_lse", "qhead_argmax", "qhead_bwd_dh", "qhead_bwd_de",
+          "qhead_small", "encoder_bwd", "gather_bwd", "adam", "topk_tilemax", "topk_select")
+
+
+def prof_read():
+    """{phase: (summed kernel ms, launches)} since the last read (synchronises the recorded events)."""
+    ms = (C.c_double * len(PHASES))()
+    cnt = (i64 * len(PHASES))()
+    check(load().cqlrec_prof_read(ms, cnt), "prof_read")
+    return {p: (float(ms[i]), int(cnt[i])) for i, p in enumerate(PHASES)}
 
 
 class CqlrecError(RuntimeError):

@@ -36,6 +36,15 @@ void cql_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// ---- measurement hooks (see cqlrec_prof_enable) -------------------------------------------------------------
+void cql_prof_begin(int phase, hipStream_t s);
+void cql_prof_end(hipStream_t s);
+struct CqlProfScope {
+  hipStream_t s;
+  CqlProfScope(int phase, hipStream_t st) : s(st) { cql_prof_begin(phase, st); }
+  ~CqlProfScope() { cql_prof_end(s); }
+};
+
 static inline int cql_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- bf16 <-> f32 ------------------------------------------------------------------------------------------

@@ -15,6 +15,65 @@ void cql_set_error(const char* fmt, ...) {
 extern "C" const char* cqlrec_last_error(void) { return g_err; }
 extern "C" int cqlrec_abi_version(void) { return CQLREC_ABI_VERSION; }
 
+// =============================================================================================================
+// measurement hooks: event pairs around kernels, on the launching stream
+// =============================================================================================================
+#define CQL_PROF_POOL 8192
+static struct {
+  bool on = false;
+  bool created = false;
+  hipEvent_t ev[CQL_PROF_POOL][2];
+  int phase[CQL_PROF_POOL];
+  int n = 0;
+  int open = -1;
+} g_prof;
+
+void cql_prof_begin(int phase, hipStream_t s) {
+  if (!g_prof.on || g_prof.n >= CQL_PROF_POOL) return;
+  g_prof.open = g_prof.n++;
+  g_prof.phase[g_prof.open] = phase;
+  (void)hipEventRecord(g_prof.ev[g_prof.open][0], s);
+}
+void cql_prof_end(hipStream_t s) {
+  if (!g_prof.on || g_prof.open < 0) return;
+  (void)hipEventRecord(g_prof.ev[g_prof.open][1], s);
+  g_prof.open = -1;
+}
+extern "C" int cqlrec_prof_enable(int32_t on) {
+  if (on && !g_prof.created) {
+    for (int i = 0; i < CQL_PROF_POOL; ++i)
+      for (int k = 0; k < 2; ++k)
+        if (hipEventCreate(&g_prof.ev[i][k]) != hipSuccess) {
+          cql_set_error("prof_enable: hipEventCreate failed");
+          return CQLREC_ERR_HIP;
+        }
+    g_prof.created = true;
+  }
+  g_prof.on = on != 0;
+  g_prof.n = 0;
+  g_prof.open = -1;
+  return CQLREC_OK;
+}
+extern "C" int cqlrec_prof_read(double* ms_sum, int64_t* launches) {
+  CQL_REQUIRE(ms_sum && launches, "prof_read: NULL pointer");
+  for (int p = 0; p < CQLREC_PH_COUNT; ++p) {
+    ms_sum[p] = 0.0;
+    launches[p] = 0;
+  }
+  for (int i = 0; i < g_prof.n; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) {
+      cql_set_error("prof_read: event query failed");
+      return CQLREC_ERR_HIP;
+    }
+    ms_sum[g_prof.phase[i]] += ms;
+    launches[g_prof.phase[i]] += 1;
+  }
+  g_prof.n = 0;
+  return CQLREC_OK;
+}
+
 extern "C" int cqlrec_layout_make(int64_t n_items, int32_t d, cqlrec_layout* out) {
   CQL_REQUIRE(out != nullptr, "layout_make: out is NULL");
   CQL_REQUIRE(n_items > 0 && n_items < (1ll << 31) - 64, "layout_make: n_items=%lld out of range", (long long)n_items);
@@ -77,6 +136,7 @@ extern "C" int cqlrec_sample_transitions(const int64_t* offsets, const int32_t* 
   CQL_REQUIRE(offsets && items && rewards && users && tpos && act && rew && done, "sample_transitions: NULL pointer");
   CQL_REQUIRE(n_users > 0 && batch > 0, "sample_transitions: n_users=%lld batch=%d", (long long)n_users, batch);
   const uint64_t k1 = mix64(seed ^ (step * 0xD1B54A32D192ED03ull));
+  CqlProfScope prof(CQLREC_PH_SAMPLE, (hipStream_t)stream);
   hipLaunchKernelGGL(sample_kernel, dim3(cql_ceil_div(batch, 256)), dim3(256), 0, (hipStream_t)stream, offsets, items,
                      rewards, n_users, k1, slot0, batch, users, tpos, act, rew, done);
   CQL_LAUNCH_CHECK("sample_transitions");
@@ -169,6 +229,7 @@ extern "C" int cqlrec_gather_pool_fwd(const uint16_t* E_in_b, const int64_t* off
   if (n_states == 0) return CQLREC_OK;
   dim3 grid(cql_ceil_div(n_states, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  CqlProfScope prof(CQLREC_PH_GATHER_FWD, s);
 #define GP_LAUNCH(DD)                                                                                          \
   hipLaunchKernelGGL(gather_pool_fwd_kernel<DD>, grid, block, 0, s, E_in_b, offsets, items, users, ends, end_delta, \
                      n_states, L, h0, h0_b, lens)
@@ -215,6 +276,7 @@ extern "C" int cqlrec_gather_pool_bwd(const float* dh0, const int64_t* offsets, 
   if (n_states <= 0) return CQLREC_OK;
   dim3 grid(cql_ceil_div(n_states, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  CqlProfScope prof(CQLREC_PH_GATHER_BWD, s);
 #define GB_LAUNCH(DD)                                                                                              \
   hipLaunchKernelGGL(gather_pool_bwd_kernel<DD>, grid, block, 0, s, dh0, offsets, items, users, ends, end_delta, \
                      n_states, L, g_E_in)
@@ -272,6 +334,7 @@ extern "C" int cqlrec_linear_bf16(const uint16_t* X_b, const uint16_t* W_b, cons
   if (rows <= 0) return CQLREC_OK;
   dim3 grid(cql_ceil_div(rows, 32)), block(64);
   hipStream_t s = (hipStream_t)stream;
+  CqlProfScope prof(CQLREC_PH_ENCODER_FWD, s);
 #define LIN_LAUNCH(DD) hipLaunchKernelGGL(linear_bf16_kernel<DD>, grid, block, 0, s, X_b, W_b, bias, rows, relu, Y, Y_b)
   if (d == 64) LIN_LAUNCH(64); else if (d == 128) LIN_LAUNCH(128); else LIN_LAUNCH(256);
 #undef LIN_LAUNCH
@@ -450,6 +513,7 @@ extern "C" int cqlrec_encoder_bwd(const float* dH, const uint16_t* z_b, const ui
   float* slab_w = dA1 + rows * d;
   float* slab_b = slab_w + (int64_t)2 * nchunk * d * d;
   hipStream_t s = (hipStream_t)stream;
+  CqlProfScope prof(CQLREC_PH_ENCODER_BWD, s);
 #define ENC_LAUNCH(DD)                                                                                               \
   do {                                                                                                               \
     hipLaunchKernelGGL(enc_bwd_dx_kernel<DD>, dim3(cql_ceil_div(rows, 32)), dim3(256), 0, s, dH, z_b, W1_b, W2_b,   \
@@ -499,6 +563,7 @@ extern "C" int cqlrec_gather_dot(const uint16_t* H_b, const uint16_t* E_b, const
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "gather_dot: d=%d unsupported", d);
   if (rows <= 0) return CQLREC_OK;
   hipStream_t s = (hipStream_t)stream;
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
   const int rpb = 4 * 64 / (d / 8);
   dim3 grid(cql_ceil_div(rows, rpb)), block(256);
 #define GD_LAUNCH(DD) hipLaunchKernelGGL(gather_dot_kernel<DD>, grid, block, 0, s, H_b, E_b, b, idx, rows, out)
@@ -539,6 +604,7 @@ extern "C" int cqlrec_td_loss(const float* q_a, const float* lse, const float* q
                               float* y, float* loss_out, cqlrec_stream stream) {
   CQL_REQUIRE(q_a && lse && q_targ && rew && done && coef, "td_loss: NULL pointer");
   CQL_REQUIRE(batch > 0, "td_loss: batch=%d", batch);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, (hipStream_t)stream);
   hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q_a, lse, q_targ, rew, done, batch,
                      gamma, alpha, inv_batch, coef, y, loss_out);
   CQL_LAUNCH_CHECK("td_loss");
@@ -588,6 +654,7 @@ extern "C" int cqlrec_adam_ema(float* theta, float* grads, float* m, float* v, f
   const int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
+  CqlProfScope prof(CQLREC_PH_ADAM, (hipStream_t)stream);
   hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)theta, (float4*)grads,
                      (float4*)m, (float4*)v, (float4*)target, (uint2*)theta_b, (uint2*)target_b, n4, step_size, sqrt_bc2,
                      beta1, beta2, eps, tau, zero_grads);

@@ -322,6 +322,9 @@ static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
 }
 
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
+  static const int phase_of[6] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
+                                  CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE};
+  CqlProfScope prof(phase_of[mode], s);
   switch (mode) {
     case QM_LSE: return qs_launch_mode<QM_LSE, QS_SPW_FWD>(a, d, rblks, s);
     case QM_ARGMAX: return qs_launch_mode<QM_ARGMAX, QS_SPW_FWD>(a, d, rblks, s);
@@ -465,10 +468,12 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
   const int thr = 256;
   if (mode == CQLREC_QHEAD_LSE) {
     qs_launch(QM_LSE, a, d, sp.rblks, s);
+    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     hipLaunchKernelGGL(qhead_finalize_lse_kernel, dim3(cql_ceil_div(rows, thr)), dim3(thr), 0, s, a.part_a, a.part_b,
                        a.nsplit, rows, out_val, out_nlse2);
   } else {
     qs_launch(QM_ARGMAX, a, d, sp.rblks, s);
+    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     hipLaunchKernelGGL(qhead_finalize_argmax_kernel, dim3(cql_ceil_div(rows, thr)), dim3(thr), 0, s, a.part_a, a.part_i,
                        a.nsplit, rows, out_val, out_idx);
   }
@@ -508,6 +513,7 @@ extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const f
     a.slab = (float*)ws;
     a.tg = 1;
     qs_launch(QM_BWD_DH, a, d, sp.rblks, s);
+    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     const int64_t n4 = batch * (d / 4);
     dim3 grid(cql_ceil_div(n4, 256)), block(256);
 #define RED_DH(DD)                                                                                                  \
@@ -532,6 +538,7 @@ extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const f
     a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * n_items * d * 4));
     a.tg = 1;
     qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
+    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     const int64_t n4 = n_items * (d / 4);
     dim3 grid(cql_ceil_div(n4, 256)), block(256);
 #define RED_DE(DD)                                                                                              \

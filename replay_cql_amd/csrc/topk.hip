@@ -259,6 +259,7 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   const int64_t buf_bytes_b = (int64_t)(((int64_t)ngroups * 4 + 15) / 16 * 16) + (int64_t)TK_CB * 8;
   const size_t smem = (size_t)(1024 + 128 + (buf_bytes_a > buf_bytes_b ? buf_bytes_a : buf_bytes_b));
   dim3 grid((unsigned)n_users), block(64);
+  CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
 #define TK_LAUNCH(DD)                                                                                                 \
   hipLaunchKernelGGL(topk_select_kernel<DD>, grid, block, smem, s, H_b, n_users, E_b, b, n_cand, item_ids, seen_off, \
                      seen_items, seen_rows, (const float*)ws, ngroups, tg, k, out_idx, out_val, out_cnt)
