@@ -167,8 +167,8 @@ class CQLCore:
 
     def allreduce_grads(self) -> None:
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            from .dist import allreduce_sum_
+            allreduce_sum_(self.grads, self.pg)
 
     def train(self, n_steps: int) -> torch.Tensor:
         """n_steps CQL steps; returns the per-step (rank-local share of the) loss as a device tensor -- no host sync

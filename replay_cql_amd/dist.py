@@ -1,0 +1,59 @@
+"""Data-parallel plumbing (one process per GPU; torch.distributed backend "nccl" = RCCL over xGMI on ROCm, "gloo" on
+CPU for tests).  The path shards by user: every rank samples transitions from its own CSR shard, the
+only exchange step is the SUM all-reduce of the flat fp32 gradient buffer between the two halves of the step;
+Adam then runs identically on every rank, so parameters stay bit-identical across ranks without a broadcast."""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+
+
+def shard_range(n_users: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous user_idx range of `rank` (transitions never cross users, so shards are independent)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return rank * n_users // world, (rank + 1) * n_users // world
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (as torch.distributed.run sets them)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return rank, world, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kwargs = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, dist.group.WORLD
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None, bucket_elems: int = 0) -> torch.Tensor:
+    """In-place SUM all-reduce of the flat gradient buffer.  bucket_elems > 0 splits it into fixed-size buckets
+    (async ops, waited together) so that RCCL can pipeline reduce-scatter / all-gather phases over the xGMI links."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flat
+    if bucket_elems <= 0 or bucket_elems >= flat.numel():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return flat
+    works = []
+    for lo in range(0, flat.numel(), bucket_elems):
+        works.append(dist.all_reduce(flat[lo: lo + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return flat
+
+
+def max_over_ranks(value: float, device, group=None) -> float:
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -1,0 +1,51 @@
+"""Generates tests/golden/*.npz from the oracle (PARITY UNPINNED: the reference has no CQL path and no vectors for
+it -- SURVEY.md 8(c) -- so these fixtures pin the build's own CPU restatement against regressions, and are what the
+GPU box checks the HIP path against at the fixture sizes).   python tests/golden/make_golden.py"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from oracle import cql_oracle as O  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+CASES = {
+    # name: (U, N, d, L, B, steps, dyadic, log_seed)
+    "tiny_dyadic": (4, 4, 64, 2, 8, 2, True, 1),
+    "small_random": (64, 257, 64, 5, 32, 4, False, 2),
+    "small_dyadic": (64, 257, 64, 5, 32, 1, True, 2),
+    "medium_random": (300, 1000, 128, 8, 64, 3, False, 3),
+}
+
+
+def make(name):
+    U, Nn, d, L, B, steps, dyadic, ls = CASES[name]
+    u, i, t, r = O.synth_log(U, Nn, seed=ls, mean_len=6 if U < 10 else 14, min_len=3, max_len=45)
+    off, items, rew = O.build_csr(u, i, t, r, U)
+    m = O.OracleModel.create(Nn, d, seed=7, dyadic=dyadic)
+    pos = O.sample_positions(11, 0, 0, B, int(off[-1]))
+    users, tpos = O.positions_to_transitions(pos, off)
+    out = O.loss_and_grads(m.layout, m.theta, m.target, off, items, rew, users, tpos, L, 0.99, 1.0)
+    losses = O.train_steps(m, off, items, rew, steps, B, L, seed=11)
+    k = min(10, Nn)
+    idx, val, cnt, _ = O.predict_topk(m.layout, m.theta, off, items, np.arange(U), k, L, filter_seen=True)
+    lay = m.layout
+    np.savez_compressed(
+        OUT / f"{name}.npz",
+        case=np.array([U, Nn, d, L, B, steps, int(dyadic), ls]),
+        log_user=u, log_item=i, log_ts=t, log_rel=r,
+        users=users, tpos=tpos, q_a=out.q_a, lse=out.lse, a_star=out.a_star, q_targ=out.q_targ, y=out.y,
+        loss0=np.float64(out.loss), grad_norms=np.array([np.linalg.norm(lay.view(out.grads, n)) for n in
+                                                         ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2")]),
+        losses=np.array(losses), theta_sum=np.float64(m.theta.astype(np.float64).sum()),
+        theta_probe=m.theta[:: max(1, lay.total // 257)][:257].copy(),
+        topk_idx=idx, topk_val=val, topk_cnt=cnt)
+
+
+if __name__ == "__main__":
+    for n in CASES:
+        make(n)
+        print("wrote", n)
