@@ -16,7 +16,12 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libcqlrec.so"
 SOURCES = ["misc.hip", "qhead.hip", "topk.hip", "train.hip"]
 # misc.hip holds the Adam kernel whose expression order is normative: no fma contraction anywhere in that file
-EXTRA = {"misc.hip": ["-ffp-contract=off"]}
+EXTRA = {
+    "misc.hip": ["-ffp-contract=off"],
+    # MFMA results straight into VGPRs (gfx950 has a unified file): no v_accvgpr_read per accumulator register
+    "qhead.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
 ARCH = "gfx950"
 
 

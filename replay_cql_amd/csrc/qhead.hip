@@ -21,22 +21,73 @@ struct QCfg {
   static constexpr int CPR = D / 8;                      // 16-byte chunks per row
   static constexpr int ROWB = D * 2;                     // bytes per row
   static constexpr int KS = D / 16;                      // MFMA k-steps per dot product
-  static constexpr int TI = (D == 256) ? 32 : QS_TI;    // streamed rows per stage (64 KiB static LDS limit)
+  static constexpr int TI = (D == 256) ? 32 : QS_TI;    // streamed rows per stage
   static constexpr int STAGE_BYTES = TI * ROWB;
-  static constexpr int NLD = STAGE_BYTES / 16 / 256;     // 16-byte chunks per thread per stage
+  static constexpr int LPS = STAGE_BYTES / 1024 / 4;     // LDS-DMA instructions per wave per stage (1 KiB each)
+  static constexpr int RPI = 64 / CPR;                   // rows covered by one LDS-DMA wave-instruction
+  static constexpr int SC_BYTES = 4 * 64 * 4;            // per stage: one private 64-float scalar strip per wave
+  static constexpr int BUF_BYTES = STAGE_BYTES + SC_BYTES;
 };
 
 #define NEG_INF (-__builtin_inff())
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <int D, int SPW, int MODE>
+// LDS image of a streamed tile: row r, 16-byte chunk ch lives at r*ROWB + (ch ^ f(r))*16.  f is chosen so that
+//  * the MFMA A-operand row read (ds_read_b128, 16-lane groups with distinct rows mod 16, equal chunk) and
+//  * the transposed read (ds_read_b64_tr_b16, per 32-lane half: 4 consecutive rows x 4 consecutive chunks)
+// are both bank-conflict free (cdna_hip_programming.md T10 "one image for row reads AND transposed reads", form (b)).
+template <int D>
+__device__ __forceinline__ int swz2(int row, int ch) {
+  if constexpr (D == 64) return ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+  else return ch ^ (((row & 3) << 2) | ((row >> 2) & 3));
+}
+
+// LDS-DMA through inline asm: hipcc models the builtin as an LDS store and would drain it (s_waitcnt vmcnt(0)) in
+// front of the next ds_read; an asm statement is invisible to that bookkeeping, so the DMA queue is ours to count
+// (cdna_hip_programming.md 5.7).  M0 carries the wave-uniform LDS byte address and is restored in the same statement.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(lds_void_t*)p;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else static_assert(N < 0, "add the vmcnt literal");
+}
+
+// NBUF LDS stage buffers, filled by LDS-DMA (global_load_lds, no VGPR staging) NBUF-1 stages ahead of the MFMAs;
+// one raw s_barrier per stage, counted vmcnt (never a drain inside the loop).
+template <int D, int SPW, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
   using C = QCfg<D>;
   constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE);
   constexpr int FT = D / 32;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_tile[2][C::STAGE_BYTES];
-  __shared__ __attribute__((aligned(16))) float lds_sc[2][C::TI];
+  constexpr int PD = NBUF - 1;               // prefetch distance in stages
+  constexpr int VPS = C::LPS + 1;            // vmcnt units per stage per wave (tile pieces + scalar strip)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object of this kernel
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int split = blockIdx.x % a.nsplit;
   const int64_t rblk = blockIdx.x / a.nsplit;
@@ -57,6 +108,9 @@ __global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
       rf[g][s] = *reinterpret_cast<const bf16x8*>(a.res + row * D + 16 * s + 8 * h);
     rs[g] = BWD ? a.res_scalar[row] : 0.f;
   }
+  // the prologue's ordinary loads must have landed before LDS-DMA traffic starts (hipcc would otherwise drain the
+  // DMA queue at their first use inside the loop)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- per-mode state -------------------------------------------------------------------------------------
   float st_a[SPW], st_b[SPW];
@@ -77,57 +131,56 @@ __global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
         for (int i = 0; i < 16; ++i) y[g][ft][i] = 0.f;
   }
 
-  // ---- stage staging --------------------------------------------------------------------------------------
-  uint4 pre[C::NLD];
-  float sc_pre = NEG_INF;
+  // ---- LDS-DMA staging: piece (wave, i) fills LDS bytes [(i*4 + wave) KiB, +1 KiB) of the stage buffer -------
+  const int dma_row = lane / C::CPR, dma_chp = lane % C::CPR;   // row within the piece, LDS chunk slot
+  const uint32_t smem_base = lds_addr(smem);
   auto issue = [&](int stage) {
+    const uint32_t bufp = __builtin_amdgcn_readfirstlane(smem_base + (stage % NBUF) * C::BUF_BYTES);
     const int64_t t0 = s_begin + (int64_t)stage * C::TI;
 #pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
-      const int c = tid + i * 256;
-      const int row = c / C::CPR, ch = c % C::CPR;
+    for (int i = 0; i < C::LPS; ++i) {
+      const int piece = i * 4 + wave;
+      const int row = piece * C::RPI + dma_row;
       int64_t srow = t0 + row;
       if (srow >= a.n_str) srow = a.n_str - 1;
-      pre[i] = *reinterpret_cast<const uint4*>(a.str + srow * D + ch * 8);
+      const uint16_t* src = a.str + srow * D + swz2<D>(row, dma_chp) * 8;
+      glds16(src, __builtin_amdgcn_readfirstlane(bufp + piece * 1024));
     }
-    if (tid < C::TI) {
-      const int64_t srow = t0 + tid;
-      sc_pre = (srow < s_end) ? a.str_scalar[srow] : NEG_INF;
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < C::NLD; ++i) {
-      const int c = tid + i * 256;
-      const int row = c / C::CPR, ch = c % C::CPR;
-      *reinterpret_cast<uint4*>(&lds_tile[buf][row * C::ROWB + swz_chunk<D>(row, ch) * 16]) = pre[i];
-    }
-    if (tid < C::TI) lds_sc[buf][tid] = sc_pre;
+    int64_t srow = t0 + lane;
+    if (srow >= a.n_str) srow = a.n_str - 1;
+    glds4(a.str_scalar + srow, __builtin_amdgcn_readfirstlane(bufp + C::STAGE_BYTES + wave * 256));
   };
 
   // transposed-read lane geometry (T10): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
   const int tr_fsub = ((lane >> 4) & 1) * 16, tr_q = (lane & 15) >> 2, tr_p = lane & 3;
 
-  if (nstage > 0) {
-    issue(0);
-    commit(0);
-  }
-  __syncthreads();
+#pragma unroll
+  for (int s0 = 0; s0 < PD; ++s0)
+    if (s0 < nstage) issue(s0);
 
   for (int stage = 0; stage < nstage; ++stage) {
-    const int buf = stage & 1;
-    if (stage + 1 < nstage) issue(stage + 1);
+    // stage `stage` has landed once at most the younger in-flight stages' pieces are outstanding
+    const int younger = (nstage - 1 - stage < PD - 1) ? (nstage - 1 - stage) : (PD - 1);
+    if (PD >= 3 && younger == 2) wait_vmcnt<2 * VPS>();
+    else if (PD >= 2 && younger == 1) wait_vmcnt<VPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's pieces of this stage landed; everyone left stage-1's buffer
+    if (stage + PD < nstage) issue(stage + PD);
+
+    const unsigned char* tile = smem + (stage % NBUF) * C::BUF_BYTES;
+    const float* sc = reinterpret_cast<const float*>(tile + C::STAGE_BYTES + wave * 256);
 
 #pragma unroll
     for (int it = 0; it < C::TI / 32; ++it) {
       const int trow = it * 32;
       const int64_t tile_row0 = s_begin + (int64_t)stage * C::TI + trow;  // global streamed row of tile row 0
       if (tile_row0 >= s_end) continue;
+      const bool partial = tile_row0 + 32 > s_end;                         // block-uniform
       // 16 per-register scalars of the streamed rows this lane's accumulator registers correspond to
       f32x16 sv;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 t4 = *reinterpret_cast<const float4*>(&lds_sc[buf][trow + 8 * q + 4 * h]);
+        const float4 t4 = *reinterpret_cast<const float4*>(&sc[trow + 8 * q + 4 * h]);
         sv[4 * q + 0] = t4.x;
         sv[4 * q + 1] = t4.y;
         sv[4 * q + 2] = t4.z;
@@ -146,9 +199,21 @@ __global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
 #pragma unroll
       for (int s = 0; s < C::KS; ++s) {
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(
-            &lds_tile[buf][(trow + r) * C::ROWB + swz_chunk<D>(trow + r, 2 * s + h) * 16]);
+            &tile[(trow + r) * C::ROWB + swz2<D>(trow + r, 2 * s + h) * 16]);
 #pragma unroll
         for (int g = 0; g < SPW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, rf[g][s], acc[g], 0, 0, 0);
+      }
+      if (partial) {   // rows past the end of the slice: -inf scores (forward) / zero probabilities (backward)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool ok = tile_row0 + mfma_row(i, h) < s_end;
+          if constexpr (MODE == QM_BWD_DE) {
+            sv[i] = ok ? sv[i] : NEG_INF;
+          } else {
+#pragma unroll
+            for (int g = 0; g < SPW; ++g) acc[g][i] = ok ? acc[g][i] : NEG_INF;
+          }
+        }
       }
 
       // ---------------- epilogues --------------------------------------------------------------------------
@@ -231,8 +296,7 @@ __global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
             for (int jj = 0; jj < 2; ++jj) {
               const int row = trow + 16 * s2 + 8 * jj + 4 * h + tr_q;
               const int col = ft * 32 + tr_fsub + 4 * tr_p;
-              const unsigned char* p8 =
-                  &lds_tile[buf][row * C::ROWB + swz_chunk<D>(row, col >> 3) * 16 + (tr_p & 1) * 8];
+              const unsigned char* p8 = &tile[row * C::ROWB + swz2<D>(row, col >> 3) * 16 + (tr_p & 1) * 8];
               const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p8);
               af[4 * jj + 0] = t4[0];
               af[4 * jj + 1] = t4[1];
@@ -246,9 +310,6 @@ __global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
         }
       }
     }
-
-    if (stage + 1 < nstage) commit(buf ^ 1);
-    __syncthreads();
   }
 
   // ---- write partials -------------------------------------------------------------------------------------
@@ -312,12 +373,25 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows) {
   return s;
 }
 
+template <int D, int SPW, int MODE>
+static void qs_launch_d(const QArgs& a, int64_t rblks, hipStream_t s) {
+  constexpr int NBUF = QS_NBUF;
+  constexpr int smem = NBUF * QCfg<D>::BUF_BYTES;
+  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)qstream_kernel<D, SPW, MODE, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              smem);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(rblks * a.nsplit)), block(256);
+  hipLaunchKernelGGL((qstream_kernel<D, SPW, MODE, NBUF>), grid, block, smem, s, a);
+}
+
 template <int MODE, int SPW>
 static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
-  dim3 grid((unsigned)(rblks * a.nsplit)), block(256);
-  if (d == 64) hipLaunchKernelGGL((qstream_kernel<64, SPW, MODE>), grid, block, 0, s, a);
-  else if (d == 128) hipLaunchKernelGGL((qstream_kernel<128, SPW, MODE>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((qstream_kernel<256, SPW, MODE>), grid, block, 0, s, a);
+  if (d == 64) qs_launch_d<64, SPW, MODE>(a, rblks, s);
+  else if (d == 128) qs_launch_d<128, SPW, MODE>(a, rblks, s);
+  else qs_launch_d<256, SPW, MODE>(a, rblks, s);
   return 0;
 }
 
@@ -343,9 +417,11 @@ __global__ void qhead_finalize_lse_kernel(const float* __restrict__ pm, const fl
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float M = NEG_INF;
+#pragma unroll 8
   for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pm[(int64_t)s * rows + r]);
   const float ms = (M == NEG_INF) ? 0.f : M;
   float L = 0.f;
+#pragma unroll 8
   for (int s = 0; s < nsplit; ++s) L += pl[(int64_t)s * rows + r] * fast_exp2((pm[(int64_t)s * rows + r] - ms) * CQL_LOG2E);
   const float v = ms + logf(L);
   lse[r] = v;
@@ -358,6 +434,7 @@ __global__ void qhead_finalize_argmax_kernel(const float* __restrict__ pv, const
   if (r >= rows) return;
   float bv = NEG_INF;
   int bi = 0x7FFFFFFF;
+#pragma unroll 8
   for (int s = 0; s < nsplit; ++s) {
     const float v = pv[(int64_t)s * rows + r];
     const int i = pi[(int64_t)s * rows + r];

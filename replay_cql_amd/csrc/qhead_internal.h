@@ -12,6 +12,7 @@
 #define QS_SPW_FWD 2        // 32-row owner groups per wave, forward modes (64 states per wave, 256 per block)
 #define QS_SPW_BWD 1        // backward modes (32 owners per wave, 128 per block)
 #define QS_TARGET_BLOCKS 768
+#define QS_NBUF 3             // LDS stage buffers (prefetch distance NBUF-1 stages)
 
 struct QArgs {
   const uint16_t* res;       // owner rows   [n_res x D] bf16
