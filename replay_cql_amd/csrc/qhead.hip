@@ -14,7 +14,13 @@
 //
 // The streamed range is cut into `nsplit` slices; slice partials are merged by tiny finalize/reduce kernels
 // (deterministic order).  blockIdx % nsplit = slice, so the blocks of one XCD (blockIdx % 8) share few slices.
+#include <stdlib.h>
 #include "qhead_internal.h"
+
+static int qs_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 
 template <int D>
 struct QCfg {
@@ -77,8 +83,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NBUF LDS stage buffers, filled by LDS-DMA (global_load_lds, no VGPR staging) NBUF-1 stages ahead of the MFMAs;
 // one raw s_barrier per stage, counted vmcnt (never a drain inside the loop).
-template <int D, int SPW, int MODE, int NBUF>
-__global__ __launch_bounds__(256) void qstream_kernel(QArgs a) {
+template <int D, int SPW, int MODE, int NBUF, int MINW>
+__global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
   using C = QCfg<D>;
   constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE);
   constexpr int FT = D / 32;
@@ -360,7 +366,8 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows) {
   QSplit s;
   s.rblks = (n_res + 128 * spw - 1) / (128 * spw);
   const int64_t units = (n_str + unit_rows - 1) / unit_rows;
-  int64_t want = (QS_TARGET_BLOCKS + s.rblks - 1) / s.rblks;
+  static const int target = qs_env_int("CQL_QS_BLOCKS", QS_TARGET_BLOCKS);
+  int64_t want = (target + s.rblks - 1) / s.rblks;
   int64_t max_split = units / 2;  // at least two units of streamed rows per slice
   if (max_split < 1) max_split = 1;
   if (want > max_split) want = max_split;
@@ -373,18 +380,29 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows) {
   return s;
 }
 
-template <int D, int SPW, int MODE>
-static void qs_launch_d(const QArgs& a, int64_t rblks, hipStream_t s) {
-  constexpr int NBUF = QS_NBUF;
+template <int D, int SPW, int MODE, int NBUF, int MINW>
+static void qs_launch_n(const QArgs& a, int64_t rblks, hipStream_t s) {
   constexpr int smem = NBUF * QCfg<D>::BUF_BYTES;
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)qstream_kernel<D, SPW, MODE, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              smem);
+    (void)hipFuncSetAttribute((const void*)qstream_kernel<D, SPW, MODE, NBUF, MINW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   dim3 grid((unsigned)(rblks * a.nsplit)), block(256);
-  hipLaunchKernelGGL((qstream_kernel<D, SPW, MODE, NBUF>), grid, block, smem, s, a);
+  hipLaunchKernelGGL((qstream_kernel<D, SPW, MODE, NBUF, MINW>), grid, block, smem, s, a);
+}
+
+template <int D, int SPW, int MODE>
+static void qs_launch_d(const QArgs& a, int64_t rblks, hipStream_t s) {
+  constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE);
+  if constexpr (BWD || D == 256) {
+    qs_launch_n<D, SPW, MODE, QS_NBUF, (D == 256 ? 1 : 2)>(a, rblks, s);
+  } else {
+    static const int minw = qs_env_int("CQL_QS_MINW", 2);
+    if (minw == 3) qs_launch_n<D, SPW, MODE, QS_NBUF, 3>(a, rblks, s);
+    else qs_launch_n<D, SPW, MODE, QS_NBUF, 2>(a, rblks, s);
+  }
 }
 
 template <int MODE, int SPW>
