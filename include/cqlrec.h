@@ -65,10 +65,19 @@ int cqlrec_sample_transitions(const int64_t* offsets, const int32_t* items, cons
 int cqlrec_gather_pool_fwd(const uint16_t* E_in_b, const int64_t* offsets, const int32_t* items,
                            const int32_t* users, const int32_t* ends, int32_t end_delta, int64_t n_states,
                            int32_t L, int32_t d, float* h0, uint16_t* h0_b, int32_t* lens, cqlrec_stream stream);
-/* backward of the above: g_E_in[item] += dh0[i] / len_i for every item of window i (fp32 atomics) */
+/* backward of the above: g_E_in[item] += dh0[i] / len_i for every item of window i.
+ * cqlrec_gather_pool_bwd: direct fp32 atomic scatter (small inputs / reference form).
+ * cqlrec_gather_pool_bwd_sorted: the production form -- (item, state) pairs are radix-sorted by item and summed
+ * per run in registers, so a hot item costs one row-add per 64 contributions; rows touched by a single chunk are
+ * written with plain stores.  g_E_in must be zero on entry for both.  ws: cqlrec_gather_pool_bwd_ws_bytes. */
 int cqlrec_gather_pool_bwd(const float* dh0, const int64_t* offsets, const int32_t* items, const int32_t* users,
                            const int32_t* ends, int32_t end_delta, int64_t n_states, int32_t L, int32_t d,
                            float* g_E_in, cqlrec_stream stream);
+int64_t cqlrec_gather_pool_bwd_ws_bytes(int64_t n_states, int32_t L, int32_t d);
+int cqlrec_gather_pool_bwd_sorted(const float* dh0, const int64_t* offsets, const int32_t* items,
+                                  const int32_t* users, const int32_t* ends, int32_t end_delta, int64_t n_states,
+                                  int32_t L, int32_t d, int64_t n_items, void* ws, int64_t ws_bytes,
+                                  float* g_E_in, cqlrec_stream stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a4  One encoder layer  Y = act(X_b W_b^T + bias)  on bf16 MFMA, fp32 accumulate (closest reference code:
@@ -181,11 +190,11 @@ typedef struct cqlrec_train_ctx {
   int32_t rank;
   float gamma, alpha, lr, beta1, beta2, eps, tau;
   uint64_t seed;
-  /* scratch: cqlrec_train_ws_bytes(batch, n_items, d) bytes */
+  /* scratch: cqlrec_train_ws_bytes(batch, n_items, d, window) bytes */
   void* ws;
   int64_t ws_bytes;
 } cqlrec_train_ctx;
-int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t d);
+int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t d, int32_t window);
 /* sample + forward + loss + backward into ctx->grads (which must be zero on entry; step_update re-zeroes it).
  * loss_out: device float (may be NULL). */
 int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,

@@ -63,6 +63,8 @@ SIGNATURES = {
     "cqlrec_sample_transitions": (i32, [vp, vp, vp, i64, u64, u64, u64, i32, vp, vp, vp, vp, vp, vp]),
     "cqlrec_gather_pool_fwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp]),
     "cqlrec_gather_pool_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp]),
+    "cqlrec_gather_pool_bwd_ws_bytes": (i64, [i64, i32, i32]),
+    "cqlrec_gather_pool_bwd_sorted": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i64, vp, i64, vp, vp]),
     "cqlrec_linear_bf16": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "cqlrec_encoder_bwd_ws_bytes": (i64, [i64, i32]),
     "cqlrec_encoder_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp]),
@@ -76,7 +78,7 @@ SIGNATURES = {
     "cqlrec_cast_bf16": (i32, [vp, vp, i64, vp]),
     "cqlrec_topk_ws_bytes": (i64, [i64, i64, i32, i32]),
     "cqlrec_score_topk": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, vp]),
-    "cqlrec_train_ws_bytes": (i64, [i32, i64, i32]),
+    "cqlrec_train_ws_bytes": (i64, [i32, i64, i32, i32]),
     "cqlrec_train_step_fwd_bwd": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
     "cqlrec_train_step_update": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), C.POINTER(TrainViews)]),

@@ -138,7 +138,7 @@ class CQLCore:
         if self._csr is None:
             raise RuntimeError("set_log() must be called before training")
         h = self.hyper
-        need = int(self.lib.cqlrec_train_ws_bytes(h.batch, self.n_items, h.d))
+        need = int(self.lib.cqlrec_train_ws_bytes(h.batch, self.n_items, h.d, h.window))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         offsets, items, rewards = self._csr

@@ -38,6 +38,9 @@ struct QCfg {
 #define NEG_INF (-__builtin_inff())
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
 
 // LDS image of a streamed tile: row r, 16-byte chunk ch lives at r*ROWB + (ch ^ f(r))*16.  f is chosen so that
 //  * the MFMA A-operand row read (ds_read_b128, 16-lane groups with distinct rows mod 16, equal chunk) and
@@ -239,21 +242,16 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
           st_a[g] = mn;
         }
       } else if constexpr (MODE == QM_ARGMAX) {
+        // branch-free: remember the FIRST 32-row tile in which this lane's running maximum was reached; the position
+        // inside that tile is resolved afterwards by qhead_argmax_resolve_kernel (one 8-MFMA chain per row)
 #pragma unroll
         for (int g = 0; g < SPW; ++g) {
           float tmax = acc[g][0];
 #pragma unroll
           for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[g][i]);
           const bool upd = tmax > st_a[g];
-          if (__any(upd)) {
-            int ii = 15;
-#pragma unroll
-            for (int i = 14; i >= 0; --i) ii = (acc[g][i] == tmax) ? i : ii;
-            if (upd) {
-              st_a[g] = tmax;
-              st_i[g] = (int)(tile_row0 + mfma_row(ii, h));
-            }
-          }
+          st_a[g] = upd ? tmax : st_a[g];
+          st_i[g] = upd ? (int)tile_row0 : st_i[g];
         }
       } else if constexpr (MODE == QM_TILEMAX) {
         const int64_t tile_idx = tile_row0 >> 5;
@@ -342,18 +340,23 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         a.part_i[pidx] = take2 ? i2 : st_i[g];
       }
     } else if constexpr (BWD) {
+      const float sc = a.out ? a.scale : 1.0f;
       if (ok) {
-        float* dst = a.slab + pidx * D;
+        float* dst = a.out ? (a.out + row * D) : (a.slab + pidx * D);
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(dst + ft * 32 + 8 * q + 4 * h) =
-                make_float4(y[g][ft][4 * q + 0], y[g][ft][4 * q + 1], y[g][ft][4 * q + 2], y[g][ft][4 * q + 3]);
+                make_float4(sc * y[g][ft][4 * q + 0], sc * y[g][ft][4 * q + 1], sc * y[g][ft][4 * q + 2],
+                            sc * y[g][ft][4 * q + 3]);
       }
       if constexpr (MODE == QM_BWD_DE) {
         const float cs = st_b[g] + __shfl_xor(st_b[g], 32);
-        if (ok && h == 0) a.slab_cs[pidx] = cs;
+        if (ok && h == 0) {
+          if (a.out) a.out_cs[row] = sc * cs;
+          else a.slab_cs[pidx] = cs;
+        }
       }
     }
   }
@@ -446,23 +449,65 @@ __global__ void qhead_finalize_lse_kernel(const float* __restrict__ pm, const fl
   if (nlse2) nlse2[r] = -v * CQL_LOG2E;
 }
 
-__global__ void qhead_finalize_argmax_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int nsplit,
-                                             int64_t rows, float* __restrict__ vmax, int32_t* __restrict__ imax) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+// ARGMAX finalize: pick, per row, the slice partial with the largest maximum (ties: the earliest tile), then resolve
+// the position inside that 32-item tile by recomputing its scores with the SAME MFMA chain as the streaming kernel
+// (bit-identical values), and take the first item whose score equals the maximum (ties -> smallest j).
+template <int D>
+__global__ __launch_bounds__(64) void qhead_argmax_resolve_kernel(const float* __restrict__ pv,
+                                                                  const int32_t* __restrict__ pt, int nsplit,
+                                                                  int64_t rows, const uint16_t* __restrict__ H_b,
+                                                                  const uint16_t* __restrict__ E_b,
+                                                                  const float* __restrict__ b, int64_t n_items,
+                                                                  float* __restrict__ vmax, int32_t* __restrict__ imax) {
+  constexpr int KS = D / 16;
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int64_t row = blockIdx.x;
   float bv = NEG_INF;
-  int bi = 0x7FFFFFFF;
-#pragma unroll 8
-  for (int s = 0; s < nsplit; ++s) {
-    const float v = pv[(int64_t)s * rows + r];
-    const int i = pi[(int64_t)s * rows + r];
-    if (v > bv || (v == bv && i < bi)) {
+  int bt = 0x7FFFFFFF;
+  for (int s = lane; s < nsplit; s += 64) {
+    const float v = pv[(int64_t)s * rows + row];
+    const int t = pt[(int64_t)s * rows + row];
+    if (v > bv || (v == bv && t < bt)) {
       bv = v;
-      bi = i;
+      bt = t;
     }
   }
-  vmax[r] = bv;
-  if (imax) imax[r] = bi;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float v = __shfl_xor(bv, off);
+    const int t = __shfl_xor(bt, off);
+    if (v > bv || (v == bv && t < bt)) {
+      bv = v;
+      bt = t;
+    }
+  }
+  if (lane == 0) vmax[row] = bv;
+  if (!imax) return;
+  if (bt == 0x7FFFFFFF) {   // nothing finite in the row
+    if (lane == 0) imax[row] = 0;
+    return;
+  }
+  const int64_t item0 = bt;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t c = item0 + mfma_row(i, h);
+    acc[i] = (c < n_items) ? b[c] : NEG_INF;
+  }
+  int64_t arow = item0 + r;
+  if (arow >= n_items) arow = n_items - 1;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const bf16x8 af = *reinterpret_cast<const bf16x8*>(E_b + arow * D + 16 * s + 8 * h);
+    const bf16x8 hf = *reinterpret_cast<const bf16x8*>(H_b + row * D + 16 * s + 8 * h);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, hf, acc, 0, 0, 0);
+  }
+  int best = 64;   // all 32 columns hold the same state: any lane pair (r, r+32) sees the 32 scores
+#pragma unroll
+  for (int i = 15; i >= 0; --i) best = (acc[i] == bv) ? mfma_row(i, h) : best;
+  const int other = __shfl_xor(best, 32);
+  best = other < best ? other : best;
+  if (lane == 0) imax[row] = (int32_t)(item0 + (best < 32 ? best : 0));
 }
 
 // dst[row][f] = scale * sum_split slab[split][row][f]  (+ coef[row] * E_b[act[row]][f] when coef != NULL)
@@ -569,8 +614,12 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
   } else {
     qs_launch(QM_ARGMAX, a, d, sp.rblks, s);
     CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
-    hipLaunchKernelGGL(qhead_finalize_argmax_kernel, dim3(cql_ceil_div(rows, thr)), dim3(thr), 0, s, a.part_a, a.part_i,
-                       a.nsplit, rows, out_val, out_idx);
+    dim3 rg((unsigned)rows), rb(64);
+#define RES_AM(DD)                                                                                                \
+  hipLaunchKernelGGL(qhead_argmax_resolve_kernel<DD>, rg, rb, 0, s, a.part_a, a.part_i, a.nsplit, rows, H_b, E_out_b, \
+                     b_out, n_items, out_val, out_idx)
+    if (d == 64) RES_AM(64); else if (d == 128) RES_AM(128); else RES_AM(256);
+#undef RES_AM
   }
   CQL_LAUNCH_CHECK("qhead_fwd");
   return CQLREC_OK;
@@ -632,15 +681,23 @@ extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const f
     a.slab = (float*)ws;
     a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * n_items * d * 4));
     a.tg = 1;
+    const bool direct = (sp.nsplit == 1);
+    if (direct) {   // one slice: the kernel scales and writes g_E_out / g_b_out itself
+      a.out = g_E_out;
+      a.out_cs = g_b_out;
+      a.scale = scale;
+    }
     qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
     CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     const int64_t n4 = n_items * (d / 4);
     dim3 grid(cql_ceil_div(n4, 256)), block(256);
+    if (!direct) {
 #define RED_DE(DD)                                                                                              \
   hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, a.slab_cs, a.nsplit, n_items, scale, \
                      (const float*)nullptr, (const int32_t*)nullptr, (const uint16_t*)nullptr, g_E_out, g_b_out)
     if (d == 64) RED_DE(64); else if (d == 128) RED_DE(128); else RED_DE(256);
 #undef RED_DE
+    }
     dim3 g2(cql_ceil_div(batch, 4));
 #define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
     if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);

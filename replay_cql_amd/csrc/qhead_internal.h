@@ -30,6 +30,10 @@ struct QArgs {
   int tg;                    // 32-row tiles per tile group (TILEMAX)
   float* slab;               // [nsplit][n_res][D] (backward)
   float* slab_cs;            // [nsplit][n_res]    (BWD_DE column sums of P)
+  // direct output (backward, nsplit == 1): out[row][D] = scale * y, out_cs[row] = scale * colsum; no slab round trip
+  float* out;
+  float* out_cs;
+  float scale;
 };
 
 struct QSplit {

@@ -21,12 +21,12 @@ struct StepWs {
   float *rew, *done, *q_a, *lse, *nlse2, *q_targ, *y, *coef, *maxv, *loss;
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
-  void *ws_q, *ws_qb, *ws_enc;
-  int64_t ws_q_bytes, ws_qb_bytes, ws_enc_bytes;
+  void *ws_q, *ws_qb, *ws_enc, *ws_gb;
+  int64_t ws_q_bytes, ws_qb_bytes, ws_enc_bytes, ws_gb_bytes;
   int64_t total;
 };
 
-StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d) {
+StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L) {
   StepWs w;
   Carve c(ws);
   w.users = c.take<int32_t>(B);
@@ -58,6 +58,8 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d) {
   w.ws_qb = c.take<char>(w.ws_qb_bytes);
   w.ws_enc_bytes = cqlrec_encoder_bwd_ws_bytes(B, d);
   w.ws_enc = c.take<char>(w.ws_enc_bytes);
+  w.ws_gb_bytes = cqlrec_gather_pool_bwd_ws_bytes(B, L, d);
+  w.ws_gb = c.take<char>(w.ws_gb_bytes);
   w.total = c.off;
   return w;
 }
@@ -72,13 +74,14 @@ int check_ctx(const cqlrec_train_ctx* c) {
               "train_step: batch=%d window=%d world=%d rank=%d", c->batch, c->window, c->world, c->rank);
   const int32_t d = c->layout.d;
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "train_step: d=%d unsupported", d);
-  CQL_REQUIRE(c->ws_bytes >= cqlrec_train_ws_bytes(c->batch, c->layout.n_items, d), "train_step: workspace too small");
+  CQL_REQUIRE(c->ws_bytes >= cqlrec_train_ws_bytes(c->batch, c->layout.n_items, d, c->window),
+              "train_step: workspace too small");
   return CQLREC_OK;
 }
 }  // namespace
 
-extern "C" int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t d) {
-  return carve_step(nullptr, batch, n_items, d).total + 256;
+extern "C" int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t d, int32_t window) {
+  return carve_step(nullptr, batch, n_items, d, window).total + 256;
 }
 
 #define CQL_TRY(expr)            \
@@ -93,7 +96,7 @@ extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t ste
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d, W = c->window;
   const int64_t N = L.n_items;
-  StepWs w = carve_step(c->ws, B, N, d);
+  StepWs w = carve_step(c->ws, B, N, d, W);
   const int64_t Bd = (int64_t)B * d;
 
   const uint16_t* Ein_b = c->theta_b + L.off_E_in;
@@ -137,7 +140,8 @@ extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t ste
                            w.ws_qb_bytes, w.dH, c->grads + L.off_E_out, c->grads + L.off_b_out, stream));
   CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, W1_b, W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
                              c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
-  CQL_TRY(cqlrec_gather_pool_bwd(w.dh0, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, c->grads + L.off_E_in, stream));
+  CQL_TRY(cqlrec_gather_pool_bwd_sorted(w.dh0, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb,
+                                        w.ws_gb_bytes, c->grads + L.off_E_in, stream));
   return CQLREC_OK;
 }
 
@@ -156,7 +160,7 @@ extern "C" int cqlrec_train_views_get(const cqlrec_train_ctx* c, cqlrec_train_vi
   CQL_TRY(check_ctx(c));
   CQL_REQUIRE(out != nullptr, "train_views_get: out is NULL");
   const int32_t B = c->batch, d = c->layout.d;
-  StepWs w = carve_step(c->ws, B, c->layout.n_items, d);
+  StepWs w = carve_step(c->ws, B, c->layout.n_items, d, c->window);
   out->users = w.users; out->tpos = w.tpos; out->act = w.act; out->a_star = w.a_star;
   out->rew = w.rew; out->done = w.done; out->q_a = w.q_a; out->lse = w.lse; out->q_targ = w.q_targ;
   out->y = w.y; out->coef = w.coef; out->dH = w.dH; out->dh0 = w.dh0; out->h0_s = w.h0_s;

@@ -96,6 +96,33 @@ def test_gather_pool_fwd(lib, d, dyadic):
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("Nn,L,n,U", [(97, 6, 200, 50), (5, 50, 700, 40), (3000, 17, 1000, 300)])
+def test_gather_pool_bwd_sorted(lib, d, Nn, L, n, U):
+    """production form (sort + segmented sum); hot items (Nn=5) exercise runs that span many chunks"""
+    off, items, _ = small_log(U=U, N=Nn, seed=3, mean_len=max(9, L), max_len=3 * L + 7)
+    rng = np.random.default_rng(1)
+    users = rng.integers(0, U, n).astype(np.int32)
+    cnt = (off[users.astype(np.int64) + 1] - off[users]).astype(np.int64)
+    ends = (rng.integers(0, 10**6, n) % (cnt + 1)).astype(np.int32)
+    dh0 = (rng.integers(-8, 9, (n, d)) * 15.0).astype(np.float32)   # /len exact for len | 60... not all: use allclose
+    g = torch.zeros(((Nn + 1), d), dtype=torch.float32, device=DEV)
+    nb = int(lib.cqlrec_gather_pool_bwd_ws_bytes(n, L, d))
+    ws = ws_bytes_tensor(nb)
+    N.check(lib.cqlrec_gather_pool_bwd_sorted(ptr(dev(dh0)), ptr(dev(off)), ptr(dev(items)), ptr(dev(users)),
+                                              ptr(dev(ends)), 0, n, L, d, Nn, ptr(ws), nb, ptr(g), stream()))
+    sync()
+    ref = np.zeros((Nn + 1, d), dtype=np.float64)
+    for i in range(n):
+        ln = min(int(ends[i]), L)
+        base = int(off[users[i]]) + int(ends[i])
+        for it in items[base - ln: base]:
+            ref[it] += dh0[i].astype(np.float32) / np.float32(ln)
+    got = g.cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-3 * np.abs(ref).max() * 1e-2)
+    assert np.all(got[Nn] == 0)
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
 def test_gather_pool_bwd(lib, d):
     Nn, L, n = 97, 6, 200
     off, items, _ = small_log(U=50, N=Nn, seed=3, mean_len=9, max_len=25)
