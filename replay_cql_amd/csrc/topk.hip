@@ -1,23 +1,62 @@
 // All-users top-K scoring (S7) without materialising the users x items score matrix.
 //
-//   pass 1  qstream_kernel<TILEMAX>: the MFMA Q-head; per (user, group of G=32*tg items) only the group maximum is
-//           written:  tilemax[group][user]  (n_cand/G floats per user instead of n_cand).
-//   pass 2  topk_select_kernel (one wave per user):
-//           a. radix-select the K' = k + n_seen(user) best groups by (max desc, group asc).  Every admissible item that
-//              belongs to the final top-k lies in one of them: each selected group holds an element >= the item, at
-//              most n_seen of those elements are excluded ones, and ties resolve towards the lower group/item id.
-//           b. re-score exactly those groups with the same MFMA chain (bit-identical to pass 1), drop seen /
-//              out-of-range items, keep candidates as 64-bit keys (order-preserving score bits << 32 | ~item id);
-//           c. radix-select the k largest keys, rank them, write (item id, score).
+//   pass 1  qstream_kernel<TILEMAX>: the MFMA Q-head; per (user, group of G = 32*tg items) only the group maximum
+//           is written, tilemax[group][user] (n_cand/G floats per user instead of n_cand), then transposed to
+//           [user][group] so that the per-user pass reads whole lines.
+//   pass 2  topk_select_kernel, one wave per user, exact "threshold algorithm":
+//           round 1: radix-select the k best groups by (max desc, group asc) from keys held in REGISTERS, re-score
+//                    those groups with the same MFMA chain as pass 1 (bit-identical scores), drop seen / out-of-range
+//                    items, keep candidates as 64-bit keys (order-preserving score bits << 32 | ~item id);
+//           round n: tau = k-th best candidate so far.  Only a group whose upper bound (its maximum, at its first item
+//                    id) still beats tau can change the answer; re-score exactly those, update tau, repeat.  Stops
+//                    when no unprocessed group can beat tau -- usually after k + (a few) groups of 32 items.
+//           finally rank the k survivors and write (item id, score).
 //   Ordering is exactly (score desc, item id asc) -- the tie rule of SURVEY.md F7 / 8.0 S7.
 #include "qhead_internal.h"
 
-#define TK_CB 2048          // candidate buffer entries (LDS)
-#define TK_MAX_K 1024
+#define TK_CB 1024          // candidate buffer entries (LDS, 8 KiB)
+#define TK_MAX_K 512
 #define TK_MAX_GROUPS 4096
 
 __device__ __forceinline__ uint64_t make_key(float score, uint32_t id) {
   return ((uint64_t)f32_order_key(score) << 32) | (uint64_t)(~id);
+}
+
+// digit selection shared by the two radix selects: with the histogram of the current digit in hist[], find the digit
+// that holds the `need`-th largest element; returns (digit, rank inside that digit's bin) wave-uniformly.
+__device__ __forceinline__ void radix_pick(const uint32_t* hist, int lane, int& need, int& digit) {
+  uint32_t bins[4];
+  uint32_t local = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    bins[b] = hist[lane * 4 + b];
+    local += bins[b];
+  }
+  uint32_t suf = local;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_down(suf, off);
+    if (lane + off < 64) suf += t;
+  }
+  const uint32_t above = suf - local;
+  const bool mine = (above < (uint32_t)need) && ((uint32_t)need <= suf);
+  int dg = 0, need_new = need;
+  if (mine) {
+    uint32_t c = above;
+#pragma unroll
+    for (int b = 3; b >= 0; --b) {
+      if (c + bins[b] >= (uint32_t)need) {
+        dg = lane * 4 + b;
+        need_new = need - (int)c;
+        break;
+      }
+      c += bins[b];
+    }
+  }
+  const unsigned long long m = __ballot(mine);
+  const int src = __ffsll((long long)m) - 1;
+  digit = __shfl(dg, src);
+  need = __shfl(need_new, src);
 }
 
 // k-th largest (1-based) of n distinct 64-bit keys in LDS `buf`; whole wave participates; hist = 256 LDS words.
@@ -33,38 +72,8 @@ __device__ uint64_t radix_kth(const uint64_t* buf, int n, int kth, uint32_t* his
       if (match) atomicAdd(&hist[(key >> shift) & 255], 1u);
     }
     __syncthreads();
-    uint32_t bins[4];
-    uint32_t local = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      bins[b] = hist[lane * 4 + b];
-      local += bins[b];
-    }
-    uint32_t suf = local;  // inclusive suffix sum over lanes >= lane
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_down(suf, off);
-      if (lane + off < 64) suf += t;
-    }
-    const uint32_t above = suf - local;
-    const bool mine = (above < (uint32_t)need) && ((uint32_t)need <= suf);
-    int digit = 0, need_new = need;
-    if (mine) {
-      uint32_t c = above;
-#pragma unroll
-      for (int b = 3; b >= 0; --b) {
-        if (c + bins[b] >= (uint32_t)need) {
-          digit = lane * 4 + b;
-          need_new = need - (int)c;
-          break;
-        }
-        c += bins[b];
-      }
-    }
-    const unsigned long long m = __ballot(mine);
-    const int src = __ffsll((long long)m) - 1;
-    digit = __shfl(digit, src);
-    need = __shfl(need_new, src);
+    int digit;
+    radix_pick(hist, lane, need, digit);
     prefix |= (uint64_t)digit << shift;
     __syncthreads();
   }
@@ -90,57 +99,106 @@ __device__ int select_topk_inplace(uint64_t* buf, int n, int k, uint32_t* hist, 
   return cnt;
 }
 
-template <int D>
+// [groups][users] -> [users][gstride]  (32x32 tiles through LDS; both sides coalesced)
+__global__ __launch_bounds__(256) void tilemax_transpose_kernel(const float* __restrict__ src, int ngroups,
+                                                                int64_t n_users, float* __restrict__ dst, int gstride) {
+  __shared__ float t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int64_t u0 = (int64_t)blockIdx.x * 32;
+  const int g0 = blockIdx.y * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = g0 + ty + 8 * j;
+    const int64_t u = u0 + tx;
+    t[ty + 8 * j][tx] = (g < ngroups && u < n_users) ? src[(int64_t)g * n_users + u] : NEG_INF_F;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t u = u0 + ty + 8 * j;
+    const int g = g0 + tx;
+    if (u < n_users && g < gstride) dst[u * gstride + g] = t[tx][ty + 8 * j];
+  }
+}
+
+template <int D, int KPL>
 __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restrict__ H_b, int64_t n_users,
                                                          const uint16_t* __restrict__ E_b, const float* __restrict__ b,
                                                          int64_t n_cand, const int32_t* __restrict__ item_ids,
                                                          const int64_t* __restrict__ seen_off,
                                                          const int32_t* __restrict__ seen_items,
                                                          const int32_t* __restrict__ seen_rows,
-                                                         const float* __restrict__ tilemax, int ngroups, int tg, int k,
-                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                         int32_t* __restrict__ out_cnt) {
+                                                         const float* __restrict__ tm_t, int gstride, int ngroups,
+                                                         int tg, int k, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_val, int32_t* __restrict__ out_cnt) {
   constexpr int KS = D / 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);                 // 256 words
-  float* scores = reinterpret_cast<float*>(smem + 1024);              // 32 floats
-  uint64_t* buf = reinterpret_cast<uint64_t*>(smem + 1024 + 128);     // max(ngroups, K' ints + TK_CB keys)
+  __shared__ uint32_t hist[256];
+  __shared__ float scores[32];
+  __shared__ uint64_t cand[TK_CB];
 
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int64_t u = blockIdx.x;
   const int64_t srow = seen_rows ? (int64_t)seen_rows[u] : u;
   const int64_t so = seen_off ? seen_off[srow] : 0;
   const int ns = seen_off ? (int)(seen_off[srow + 1] - so) : 0;
-  int kprime = k + ns;
-  if (kprime > ngroups) kprime = ngroups;
+  const unsigned long long lt_mask = (1ull << lane) - 1;
 
-  // ---- a. select the K' best groups ------------------------------------------------------------------------
-  for (int g = lane; g < ngroups; g += 64) buf[g] = make_key(tilemax[(int64_t)g * n_users + u], (uint32_t)g);
-  __syncthreads();
-  uint64_t thr = 0;
-  if (kprime < ngroups) thr = radix_kth(buf, ngroups, kprime, hist, lane);
-  int32_t* sel = reinterpret_cast<int32_t*>(buf);
-  int nsel = 0;
-  for (int base = 0; base < ngroups; base += 64) {
-    const int g = base + lane;
-    const bool keep = (g < ngroups) && (buf[g] >= thr);
-    const unsigned long long m = __ballot(keep);
-    const int pos = nsel + __popcll(m & ((1ull << lane) - 1));
+  // ---- group maxima of this user -> order-preserving keys in registers (group g = slot*64 + lane) -----------
+  uint32_t key[KPL];
+#pragma unroll
+  for (int sl = 0; sl < KPL; ++sl) {
+    const int g = sl * 64 + lane;
+    key[sl] = (g < ngroups) ? f32_order_key(tm_t[u * gstride + g]) : 0u;
+  }
+  const int kk = k < ngroups ? k : ngroups;
+
+  // ---- radix select on the 32-bit keys: T = kk-th largest value, need_eq = how many of the == T keys are wanted ----
+  uint32_t T = 0;
+  int need = kk;
+  // digits on which every key agrees need no histogram (scores of one user usually share the top byte; a shared
+  // digit would also serialise all the LDS atomics on one word)
+  uint32_t k_and = 0xFFFFFFFFu, k_or = 0u;
+#pragma unroll
+  for (int sl = 0; sl < KPL; ++sl) {
+    if (sl * 64 + lane < ngroups) {
+      k_and &= key[sl];
+      k_or |= key[sl];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    k_and &= __shfl_xor(k_and, off);
+    k_or |= __shfl_xor(k_or, off);
+  }
+  const uint32_t k_diff = k_and ^ k_or;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (((k_diff >> shift) & 255u) == 0u) {
+      T |= k_and & (255u << shift);
+      continue;
+    }
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
     __syncthreads();
-    if (keep) sel[pos] = g;   // pos <= g: lands in bytes of keys already consumed
-    nsel += __popcll(m);
+#pragma unroll
+    for (int sl = 0; sl < KPL; ++sl) {
+      const int g = sl * 64 + lane;
+      const bool match = (g < ngroups) && ((shift == 24) || ((key[sl] >> (shift + 8)) == (T >> (shift + 8))));
+      if (match) atomicAdd(&hist[(key[sl] >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    int digit;
+    radix_pick(hist, lane, need, digit);
+    T |= (uint32_t)digit << shift;
     __syncthreads();
   }
-  uint64_t* cand = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(buf) + ((nsel * 4 + 15) / 16) * 16);
-  int ncand = 0;
+  const int need_eq = need;
 
-  // ---- b. exact re-scoring of the selected groups -----------------------------------------------------------
   bf16x8 hf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(H_b + u * D + 16 * s + 8 * h);
 
-  for (int si = 0; si < nsel; ++si) {
-    const int g = sel[si];
+  int ncand = 0;
+  // exact re-scoring of one group (wave-uniform g): tg tiles of 32 candidates -> admissible ones appended to cand[]
+  auto rescore = [&](int g) {
     for (int t = 0; t < tg; ++t) {
       const int64_t item0 = ((int64_t)g * tg + t) * 32;
       if (item0 >= n_cand) break;
@@ -163,7 +221,7 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
       }
       __syncthreads();
       bool valid = false;
-      uint64_t key = 0;
+      uint64_t ck = 0;
       if (lane < 32) {
         const int64_t c = item0 + lane;
         if (c < n_cand) {
@@ -179,26 +237,81 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
             }
             if (lo < ns && seen_items[so + lo] == gid) valid = false;
           }
-          key = make_key(sc, (uint32_t)gid);
+          ck = make_key(sc, (uint32_t)gid);
         }
       }
       const unsigned long long m = __ballot(valid);
-      const int pos = ncand + __popcll(m & ((1ull << lane) - 1));
-      if (valid) cand[pos] = key;
+      const int pos = ncand + __popcll(m & lt_mask);
+      if (valid) cand[pos] = ck;
       ncand += __popcll(m);
       __syncthreads();
       if (ncand + 32 > TK_CB) ncand = select_topk_inplace(cand, ncand, k, hist, lane);
     }
+  };
+
+  // ---- round 1: the kk best groups by (max desc, group asc) ------------------------------------------------------
+  unsigned long long done = 0;   // bit sl: this lane's slot sl has been re-scored
+  int eq_base = 0;
+#pragma unroll
+  for (int sl = 0; sl < KPL; ++sl) {
+    const int g = sl * 64 + lane;
+    const bool in = g < ngroups;
+    const bool eq = in && key[sl] == T;
+    const unsigned long long em = __ballot(eq);
+    const bool pick = in && (key[sl] > T || (eq && eq_base + __popcll(em & lt_mask) < need_eq));
+    eq_base += __popcll(em);
+    unsigned long long pm = __ballot(pick);
+    if (pick) done |= 1ull << sl;
+    while (pm) {
+      const int j = __ffsll((long long)pm) - 1;
+      pm &= pm - 1;
+      rescore(sl * 64 + j);
+    }
   }
 
-  // ---- c. final selection + ranking ---------------------------------------------------------------------------
-  ncand = select_topk_inplace(cand, ncand, k, hist, lane);
+  // ---- further rounds: only groups whose upper bound still beats the k-th best candidate ---------------------------
+  for (;;) {
+    ncand = select_topk_inplace(cand, ncand, k, hist, lane);
+    uint64_t tau = 0;   // k-th best key so far (0: fewer than k admissible candidates yet -> everything qualifies)
+    if (ncand >= k) {
+      tau = ~0ull;
+      for (int i = lane; i < ncand; i += 64) tau = cand[i] < tau ? cand[i] : tau;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_xor(tau, off);
+        tau = o < tau ? o : tau;
+      }
+    }
+    const uint32_t tau_hi = (uint32_t)(tau >> 32);
+    bool any = false;
+#pragma unroll
+    for (int sl = 0; sl < KPL; ++sl) {
+      const int g = sl * 64 + lane;
+      bool pick = (g < ngroups) && !((done >> sl) & 1ull) && key[sl] >= tau_hi;
+      if (pick && key[sl] == tau_hi) {   // tie on the score: the group's smallest item id decides
+        const int64_t c0 = (int64_t)g * tg * 32;
+        const uint32_t gid0 = (c0 < n_cand) ? (uint32_t)(item_ids ? item_ids[c0] : (int32_t)c0) : 0xFFFFFFFFu;
+        pick = (((uint64_t)tau_hi << 32) | (uint64_t)(~gid0)) > tau;
+      }
+      unsigned long long pm = __ballot(pick);
+      if (pick) done |= 1ull << sl;
+      any |= (pm != 0);
+      while (pm) {
+        const int j = __ffsll((long long)pm) - 1;
+        pm &= pm - 1;
+        rescore(sl * 64 + j);
+      }
+    }
+    if (!any) break;
+  }
+
+  // ---- rank the survivors -------------------------------------------------------------------------------------------
   for (int i = lane; i < ncand; i += 64) {
-    const uint64_t key = cand[i];
+    const uint64_t ck = cand[i];
     int rank = 0;
-    for (int j = 0; j < ncand; ++j) rank += (cand[j] > key) ? 1 : 0;
-    out_idx[u * k + rank] = (int32_t)(~(uint32_t)(key & 0xFFFFFFFFull));
-    out_val[u * k + rank] = f32_from_order_key((uint32_t)(key >> 32));
+    for (int j = 0; j < ncand; ++j) rank += (cand[j] > ck) ? 1 : 0;
+    out_idx[u * k + rank] = (int32_t)(~(uint32_t)(ck & 0xFFFFFFFFull));
+    out_val[u * k + rank] = f32_from_order_key((uint32_t)(ck >> 32));
   }
   for (int i = ncand + lane; i < k; i += 64) {
     out_idx[u * k + i] = -1;
@@ -223,7 +336,8 @@ extern "C" int64_t cqlrec_topk_ws_bytes(int64_t n_users, int64_t n_cand, int32_t
   (void)k;
   int tg;
   const int ngroups = tk_tile_groups(n_cand, &tg);
-  return align256((int64_t)ngroups * n_users * 4) + 256;
+  const int gstride = (ngroups + 63) / 64 * 64;
+  return align256((int64_t)ngroups * n_users * 4) + align256((int64_t)gstride * n_users * 4) + 256;
 }
 
 extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b,
@@ -239,6 +353,9 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   CQL_REQUIRE(ws_bytes >= cqlrec_topk_ws_bytes(n_users, n_cand, d, k), "score_topk: workspace too small");
   int tg;
   const int ngroups = tk_tile_groups(n_cand, &tg);
+  const int gstride = (ngroups + 63) / 64 * 64;
+  float* tm = (float*)ws;
+  float* tm_t = (float*)((char*)ws + align256((int64_t)ngroups * n_users * 4));
   hipStream_t s = (hipStream_t)stream;
   // pass 1
   const int unit = (32 * tg > QS_TI) ? 32 * tg : QS_TI;
@@ -251,19 +368,25 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   a.str_scalar = b;
   a.nsplit = sp.nsplit;
   a.split_rows = sp.split_rows;
-  a.tilemax = (float*)ws;
+  a.tilemax = tm;
   a.tg = tg;
   qs_launch(QM_TILEMAX, a, d, sp.rblks, s);
   // pass 2
-  const int64_t buf_bytes_a = (int64_t)ngroups * 8;
-  const int64_t buf_bytes_b = (int64_t)(((int64_t)ngroups * 4 + 15) / 16 * 16) + (int64_t)TK_CB * 8;
-  const size_t smem = (size_t)(1024 + 128 + (buf_bytes_a > buf_bytes_b ? buf_bytes_a : buf_bytes_b));
-  dim3 grid((unsigned)n_users), block(64);
   CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
-#define TK_LAUNCH(DD)                                                                                                 \
-  hipLaunchKernelGGL(topk_select_kernel<DD>, grid, block, smem, s, H_b, n_users, E_b, b, n_cand, item_ids, seen_off, \
-                     seen_items, seen_rows, (const float*)ws, ngroups, tg, k, out_idx, out_val, out_cnt)
-  if (d == 64) TK_LAUNCH(64); else if (d == 128) TK_LAUNCH(128); else TK_LAUNCH(256);
+  hipLaunchKernelGGL(tilemax_transpose_kernel, dim3(cql_ceil_div(n_users, 32), cql_ceil_div(gstride, 32)), dim3(256), 0,
+                     s, tm, ngroups, n_users, tm_t, gstride);
+  dim3 grid((unsigned)n_users), block(64);
+#define TK_LAUNCH(DD, KP)                                                                                          \
+  hipLaunchKernelGGL((topk_select_kernel<DD, KP>), grid, block, 0, s, H_b, n_users, E_b, b, n_cand, item_ids, seen_off, \
+                     seen_items, seen_rows, (const float*)tm_t, gstride, ngroups, tg, k, out_idx, out_val, out_cnt)
+#define TK_BY_KPL(DD)                              \
+  do {                                             \
+    if (ngroups <= 1024) TK_LAUNCH(DD, 16);        \
+    else if (ngroups <= 2048) TK_LAUNCH(DD, 32);   \
+    else TK_LAUNCH(DD, 64);                        \
+  } while (0)
+  if (d == 64) TK_BY_KPL(64); else if (d == 128) TK_BY_KPL(128); else TK_BY_KPL(256);
+#undef TK_BY_KPL
 #undef TK_LAUNCH
   CQL_LAUNCH_CHECK("score_topk");
   return CQLREC_OK;
