@@ -232,6 +232,8 @@ class CQLCore:
         whole catalog).  seen = (offsets int64, ascending item ids int32) CSR; seen_rows maps hb rows to CSR rows."""
         h, lay = self.hyper, self.layout
         n = hb.shape[0]
+        if k > self.MAX_FUSED_K:
+            return self._score_topk_large_k(hb, k, cand_items, seen, seen_rows, chunk)
         eb, fp = self.theta_b.data_ptr(), self.theta.data_ptr()
         if cand_items is None:
             E_ptr, b_ptr, n_cand, ids_ptr = eb + 2 * lay.off_E_out, fp + 4 * lay.off_b_out, self.n_items, None
@@ -264,6 +266,33 @@ class CQLCore:
                 out_cnt.data_ptr() + 4 * lo, s), "score_topk")
         del keep
         return out_idx, out_val, out_cnt
+
+    MAX_FUSED_K = 2048
+
+    def _score_topk_large_k(self, hb, k, cand_items, seen, seen_rows, chunk):
+        """k beyond the fused kernel's limit (full-ranking requests): rank every candidate part of <= MAX_FUSED_K items
+        completely with the fused kernel, then merge the parts per user (plumbing; ordering rule unchanged)."""
+        n = hb.shape[0]
+        ci = (torch.arange(self.n_items, device=self.device) if cand_items is None
+              else cand_items.to(self.device)).to(torch.int64)
+        parts_i, parts_v = [], []
+        for lo in range(0, ci.numel(), self.MAX_FUSED_K):
+            part = ci[lo: lo + self.MAX_FUSED_K]
+            i_, v_, _ = self.score_topk(hb, int(part.numel()), part, seen, seen_rows, chunk)
+            parts_i.append(i_)
+            parts_v.append(v_)
+        idx, val = torch.cat(parts_i, 1), torch.cat(parts_v, 1)
+        # (score desc, item id asc); padding entries (-1, -inf) sink to the end
+        key_id = torch.where(idx >= 0, idx, torch.full_like(idx, 2**31 - 1)).to(torch.int64)
+        o1 = torch.argsort(key_id, dim=1, stable=True)
+        o2 = torch.argsort(val.gather(1, o1), dim=1, descending=True, stable=True)
+        order = o1.gather(1, o2)[:, :k]
+        idx, val = idx.gather(1, order), val.gather(1, order)
+        if idx.shape[1] < k:
+            pad = k - idx.shape[1]
+            idx = torch.nn.functional.pad(idx, (0, pad), value=-1)
+            val = torch.nn.functional.pad(val, (0, pad), value=float("-inf"))
+        return idx.contiguous(), val.contiguous(), (idx >= 0).sum(1).to(torch.int32)
 
     def pair_scores(self, hb: torch.Tensor, item_ids: torch.Tensor) -> torch.Tensor:
         """relevance of (hb[i], item_ids[i]) pairs (a11)."""

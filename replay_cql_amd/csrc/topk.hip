@@ -14,8 +14,9 @@
 //   Ordering is exactly (score desc, item id asc) -- the tie rule of SURVEY.md F7 / 8.0 S7.
 #include "qhead_internal.h"
 
-#define TK_CB 1024          // candidate buffer entries (LDS, 8 KiB)
-#define TK_MAX_K 512
+#define TK_CB_SMALL 1024    // candidate buffer entries (LDS, 8 KiB): k <= 512
+#define TK_CB_LARGE 4096    // 32 KiB: k <= 2048 (rare; lower occupancy)
+#define TK_MAX_K 2048
 #define TK_MAX_GROUPS 4096
 
 __device__ __forceinline__ uint64_t make_key(float score, uint32_t id) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void tilemax_transpose_kernel(const float* __r
   }
 }
 
-template <int D, int KPL>
+template <int D, int KPL, int TK_CB>
 __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restrict__ H_b, int64_t n_users,
                                                          const uint16_t* __restrict__ E_b, const float* __restrict__ b,
                                                          int64_t n_cand, const int32_t* __restrict__ item_ids,
@@ -376,9 +377,15 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   hipLaunchKernelGGL(tilemax_transpose_kernel, dim3(cql_ceil_div(n_users, 32), cql_ceil_div(gstride, 32)), dim3(256), 0,
                      s, tm, ngroups, n_users, tm_t, gstride);
   dim3 grid((unsigned)n_users), block(64);
-#define TK_LAUNCH(DD, KP)                                                                                          \
-  hipLaunchKernelGGL((topk_select_kernel<DD, KP>), grid, block, 0, s, H_b, n_users, E_b, b, n_cand, item_ids, seen_off, \
-                     seen_items, seen_rows, (const float*)tm_t, gstride, ngroups, tg, k, out_idx, out_val, out_cnt)
+#define TK_LAUNCH_CB(DD, KP, CB)                                                                                      \
+  hipLaunchKernelGGL((topk_select_kernel<DD, KP, CB>), grid, block, 0, s, H_b, n_users, E_b, b, n_cand, item_ids,        \
+                     seen_off, seen_items, seen_rows, (const float*)tm_t, gstride, ngroups, tg, k, out_idx, out_val,     \
+                     out_cnt)
+#define TK_LAUNCH(DD, KP)                                     \
+  do {                                                        \
+    if (k <= TK_CB_SMALL / 2) TK_LAUNCH_CB(DD, KP, TK_CB_SMALL); \
+    else TK_LAUNCH_CB(DD, KP, TK_CB_LARGE);                   \
+  } while (0)
 #define TK_BY_KPL(DD)                              \
   do {                                             \
     if (ngroups <= 1024) TK_LAUNCH(DD, 16);        \
@@ -388,6 +395,7 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   if (d == 64) TK_BY_KPL(64); else if (d == 128) TK_BY_KPL(128); else TK_BY_KPL(256);
 #undef TK_BY_KPL
 #undef TK_LAUNCH
+#undef TK_LAUNCH_CB
   CQL_LAUNCH_CHECK("score_topk");
   return CQLREC_OK;
 }

@@ -176,6 +176,8 @@ class PandasRecommender(ABC):
     def _predict_wrap(self, log, k: int, users=None, items=None, user_features=None, item_features=None,
                       filter_seen_items: bool = True, recs_file_path: Optional[str] = None):
         self.logger.debug("Starting predict %s", type(self).__name__)
+        if not hasattr(self, "fit_items"):
+            raise RuntimeError(f"{self} model is not fitted")
         spark_out = _is_spark(log)
         log, user_features, item_features = to_pandas(log), to_pandas(user_features), to_pandas(item_features)
         user_data = next((x for x in (users, log, user_features, self.fit_users) if x is not None), None)

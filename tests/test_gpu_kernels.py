@@ -426,7 +426,8 @@ def _topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None):
 
 
 @pytest.mark.parametrize("n_users,Nn,d,k", [(5, 40, 64, 10), (70, 1000, 128, 10), (130, 4099, 64, 25),
-                                            (33, 10007, 128, 100), (20, 513, 256, 7)])
+                                            (33, 10007, 128, 100), (20, 513, 256, 7), (9, 3000, 64, 700),
+                                            (6, 2500, 128, 2048)])
 @pytest.mark.parametrize("with_seen", [False, True])
 def test_topk_dyadic_bit_exact(lib, n_users, Nn, d, k, with_seen):
     idx, val, cnt, idx_ref, val_ref, _ = _topk_case(lib, n_users, Nn, d, k, True, Nn + k, with_seen)

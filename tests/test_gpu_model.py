@@ -1,0 +1,124 @@
+"""The `CQL` recommender on the GPU through the reference-shaped API (fit / predict / predict_pairs / save / load).
+Mirrors the contract tests of the reference for its torch models (tests/models/test_all_models.py:128-144, :378-390;
+tests/models/test_save_load_models.py:48-70; tests/models/test_neuromf.py:61-88) with the oracle as the checker."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import cql_oracle as O
+from replay_cql_amd.cql import CQL
+
+pytestmark = pytest.mark.gpu
+
+U, NI, D_, L = 120, 700, 64, 8
+
+
+@pytest.fixture(scope="module")
+def log():
+    u, i, t, r = O.synth_log(U, NI, seed=6, mean_len=14, max_len=40)
+    # make item ids sparse at the top so that _item_dim_size > number of distinct items
+    return pd.DataFrame({"user_idx": u, "item_idx": i, "timestamp": pd.to_datetime(t, unit="s"), "relevance": r})
+
+
+@pytest.fixture(scope="module")
+def model(log):
+    m = CQL(embedding_dim=D_, window=L, batch_size=64, n_steps=12, seed=3, device="cuda:0")
+    m.fit(log)
+    return m
+
+
+def _oracle_model(m):
+    lay = O.Layout.make(m.core.n_items, D_)
+    return lay, m.core.theta.cpu().numpy()
+
+
+def test_fit_trains_and_matches_oracle_trajectory(log, model):
+    assert model.train_losses.shape == (12,) and np.all(np.isfinite(model.train_losses))
+    assert model._num_users == log.user_idx.nunique() and model._item_dim_size == log.item_idx.max() + 1
+    # replay the same 12 steps on the CPU
+    off, items, rew = O.build_csr(log.user_idx, log.item_idx, log.timestamp.values, log.relevance, model._user_dim_size)
+    om = O.OracleModel.create(model._item_dim_size, D_, seed=7)
+    from replay_cql_amd.core import CQLCore, CQLHyper
+    fresh = CQLCore(model._item_dim_size, CQLHyper(d=D_, window=L, batch=64, seed=3), device="cuda:0")
+    om.theta[:] = fresh.theta.cpu().numpy()
+    om.target[:] = om.theta
+    ref = O.train_steps(om, off, items, rew, 12, 64, L, seed=3)
+    np.testing.assert_allclose(model.train_losses, ref, rtol=1e-3)
+    assert np.linalg.norm(model.core.theta.cpu().numpy() - om.theta) < 1e-3 * np.linalg.norm(om.theta)
+
+
+def test_predict_matches_oracle_topk(log, model):
+    k = 7
+    recs = model.predict(log, k=k)
+    assert list(recs.columns) == ["user_idx", "item_idx", "relevance"]
+    assert recs.groupby("user_idx").size().eq(k).all() and recs.user_idx.nunique() == log.user_idx.nunique()
+    seen = set(zip(log.user_idx, log.item_idx))
+    assert not (set(zip(recs.user_idx, recs.item_idx)) & seen)
+    lay, theta = _oracle_model(model)
+    off, items, rew = O.build_csr(log.user_idx, log.item_idx, log.timestamp.values, log.relevance, model._user_dim_size)
+    users = np.sort(log.user_idx.unique())
+    fit_items = np.sort(log.item_idx.unique())
+    ridx, rval, rcnt, hb = O.predict_topk(lay, theta, off, items, users, k, L, filter_seen=True, cand_items=fit_items)
+    Q = O.qvalues(hb, O.bf16_round(lay.view(theta, "E_out")), lay.view(theta, "b_out"))
+    diff = 0
+    for row, u in enumerate(users):
+        got = recs[recs.user_idx == u]
+        assert np.all(np.diff(got.relevance.values) <= 0)
+        for j in set(got.item_idx) ^ set(ridx[row]):
+            assert abs(Q[row, j] - rval[row, -1]) < 2e-3
+            diff += 1
+        np.testing.assert_allclose(got.relevance.values, Q[row, got.item_idx.values], atol=2e-3)
+    assert diff <= 4
+
+
+def test_predict_users_items_subsets_and_cold(log, model):
+    recs = model.predict(log, k=3, users=[0, 5, 9, 10_000], items=[1, 2, 3, 4, 5, 6, 10**6], filter_seen_items=False)
+    assert set(recs.user_idx) == {0, 5, 9} and set(recs.item_idx) <= {1, 2, 3, 4, 5, 6}
+    assert recs.groupby("user_idx").size().eq(3).all()
+    # users without history in the passed log produce no rows (reference: tests/models/test_vae.py:56-62)
+    sub = log[log.user_idx < 10]
+    recs = model.predict(sub, k=3, users=[1, 2, 50])
+    assert set(recs.user_idx) == {1, 2}
+    # k larger than the number of admissible items
+    known = np.sort(log.item_idx.unique())[:20]
+    recs = model.predict(log, k=50, users=[0], items=list(known) + [10**6], filter_seen_items=False)
+    assert len(recs) == 20 and set(recs.item_idx) == set(known)
+
+
+def test_predict_pairs(log, model):
+    known = np.sort(log.item_idx.unique())
+    pairs = pd.DataFrame({"user_idx": [0, 0, 3, 7, 7], "item_idx": known[[5, 9, 2, 2, 100]]})
+    pred = model.predict_pairs(pairs, log)
+    assert len(pred) == 5 and list(pred.columns) == ["user_idx", "item_idx", "relevance"]
+    full = model.predict(log, k=model._item_dim_size, users=[0, 3, 7], filter_seen_items=False)
+    merged = pred.merge(full, on=["user_idx", "item_idx"], suffixes=("", "_full"))
+    np.testing.assert_allclose(merged.relevance, merged.relevance_full, atol=1e-3)   # the shadowed reference test :63-96
+    assert model.predict_pairs(pairs, log, k=1).groupby("user_idx").size().max() == 1
+    with pytest.raises(ValueError, match="log is not provided"):
+        model.predict_pairs(pairs)
+
+
+def test_save_load_round_trip(tmp_path, log, model):
+    path = str(tmp_path / "model")
+    model._save_model(path)
+    m2 = CQL(device="cuda:0")
+    m2._load_model(path)
+    assert m2._init_args == model._init_args
+    pd.testing.assert_frame_equal(m2.predict(log, k=5), model.predict(log, k=5))
+    assert m2.core.step == model.core.step
+    # resume: one more step on both gives identical parameters
+    for m in (model, m2):
+        off, items, rew = O.build_csr(log.user_idx, log.item_idx, log.timestamp.values, log.relevance, m._user_dim_size)
+        m.core.set_log(off, items, rew)
+        m.core.train(1)
+    assert torch.equal(m2.core.theta, model.core.theta)
+
+
+def test_item_features_and_errors(log, model):
+    vecs, rank = model._get_features_wrap(pd.DataFrame({"item_idx": [0, 1, 2]}), None)
+    assert rank == D_ and len(vecs) == 3 and len(vecs.item_factors.iloc[0]) == D_
+    with pytest.raises(ValueError):
+        CQL(embedding_dim=100)
+    with pytest.raises(RuntimeError, match="not fitted"):
+        CQL(device="cuda:0").predict(log, k=1, users=[0])

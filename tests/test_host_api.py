@@ -1,0 +1,144 @@
+"""CPU tests of the host layer: the pandas mirror of the reference's Recommender wrappers (semantics cited from
+replay/models/base_rec.py), CSR construction, seen lists, the synthetic generator.  A deterministic fake model stands
+in for the GPU core so that the wrapper logic is tested without a GPU."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import cql_oracle as O
+from replay_cql_amd import data as D
+from replay_cql_amd.recommender_api import PandasRecommender, get_top_k_recs
+
+
+class ScoreTable(PandasRecommender):
+    """relevance(u, i) = table[u, i]; returns, like the reference's torch models, MORE than k rows per user."""
+
+    def __init__(self, table, cold_users=False):
+        self.table = table
+        self.can_predict_cold_users = cold_users
+        self.fit_calls = 0
+
+    def _fit(self, log, user_features=None, item_features=None):
+        self.fit_calls += 1
+
+    def _predict(self, log, k, users, items, user_features=None, item_features=None, filter_seen_items=True):
+        rows = [(u, i, self.table[u % self.table.shape[0], i]) for u in users["user_idx"] for i in items["item_idx"]]
+        return pd.DataFrame(rows, columns=["user_idx", "item_idx", "relevance"])
+
+
+@pytest.fixture
+def log():
+    # the shape of the reference's tiny fixture (tests/utils.py:59-76): 4 users, 4 items, 11 rows
+    return pd.DataFrame({
+        "user_idx": [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3],
+        "item_idx": [0, 1, 2, 0, 1, 3, 1, 2, 3, 0, 3],
+        "timestamp": pd.to_datetime(["2020-01-%02d" % d for d in range(1, 12)]),
+        "relevance": [1.0, 0.5, 0.25, 1.0, 0.75, 0.5, 1.0, 1.0, 0.5, 0.25, 1.0],
+    })
+
+
+TABLE = np.array([[4.0, 3.0, 2.0, 1.0], [1.0, 2.0, 3.0, 4.0], [2.0, 2.0, 2.0, 2.0], [0.5, 4.5, 1.5, 3.5]])
+
+
+def test_fit_wrap_sets_dims(log):
+    m = ScoreTable(TABLE)
+    m.fit(log)
+    assert m.fit_calls == 1 and m._num_users == 4 and m._num_items == 4
+    assert m._user_dim_size == 4 and m._item_dim_size == 4
+    assert str(m) == "ScoreTable"
+
+
+def test_predict_filters_seen_and_takes_top_k(log):
+    m = ScoreTable(TABLE)
+    recs = m.fit_predict(log, k=2)
+    assert list(recs.columns) == ["user_idx", "item_idx", "relevance"]
+    seen = set(zip(log.user_idx, log.item_idx))
+    assert not (set(zip(recs.user_idx, recs.item_idx)) & seen)
+    # user 0 saw items 0,1,2 -> only item 3 is left; user 2 saw 1,2,3 -> only item 0
+    assert recs[recs.user_idx == 0].item_idx.tolist() == [3]
+    assert recs[recs.user_idx == 2].item_idx.tolist() == [0]
+    recs2 = m.predict(log, k=2, filter_seen_items=False)
+    assert recs2.groupby("user_idx").size().tolist() == [2, 2, 2, 2]
+    assert recs2[recs2.user_idx == 0].item_idx.tolist() == [0, 1]
+    assert recs2[recs2.user_idx == 2].item_idx.tolist() == [0, 1]        # all-equal scores: item_idx asc
+    assert recs2.relevance.dtype == np.float64 and recs2.item_idx.dtype == np.int32
+
+
+def test_cold_users_and_items_are_dropped(log):
+    m = ScoreTable(TABLE)
+    m.fit(log)
+    recs = m.predict(log, k=1, users=[0, 7, 9], items=[1, 2, 3, 42], filter_seen_items=False)
+    assert set(recs.user_idx) == {0} and set(recs.item_idx) <= {1, 2, 3}
+    m2 = ScoreTable(TABLE, cold_users=True)
+    m2.fit(log)
+    recs = m2.predict(log, k=1, users=[0, 7], filter_seen_items=False)
+    assert set(recs.user_idx) == {0, 7}
+
+
+def test_predict_pairs_contract(log):
+    m = ScoreTable(TABLE)
+    m.fit(log)
+    pairs = pd.DataFrame({"user_idx": [0, 0, 1, 3], "item_idx": [1, 3, 2, 0]})
+    pred = m.predict_pairs(pairs, log)
+    assert len(pred) == 4
+    got = {(u, i): r for u, i, r in pred.itertuples(index=False)}
+    assert got[(0, 1)] == 3.0 and got[(3, 0)] == 0.5
+    assert m.predict_pairs(pairs, log, k=1).groupby("user_idx").size().max() == 1
+    with pytest.raises(ValueError, match="strictly"):
+        m.predict_pairs(pairs.assign(extra=1), log)
+
+
+def test_predict_to_parquet_equals_returned(tmp_path, log):
+    m = ScoreTable(TABLE)
+    m.fit(log)
+    path = str(tmp_path / "recs.parquet")
+    assert m.predict(log, k=2, recs_file_path=path) is None
+    pd.testing.assert_frame_equal(pd.read_parquet(path), m.predict(log, k=2))
+
+
+def test_get_ids_and_errors(log):
+    assert PandasRecommender._get_ids([3, 3, 1], "user_idx")["user_idx"].tolist() == [3, 1]
+    assert PandasRecommender._get_ids(log, "item_idx")["item_idx"].tolist() == [0, 1, 2, 3]
+    with pytest.raises(ValueError, match="Wrong type"):
+        PandasRecommender._get_ids(5, "user_idx")
+    m = ScoreTable(TABLE)
+    m.set_params(fit_calls=5)
+    assert m.fit_calls == 5
+    with pytest.raises(NotImplementedError):
+        m.get_nearest_items([1], 2)
+
+
+def test_get_top_k_recs_tie_rule():
+    df = pd.DataFrame({"user_idx": [0] * 4, "item_idx": [3, 1, 2, 0], "relevance": [1.0, 2.0, 2.0, 2.0]})
+    assert get_top_k_recs(df, 2).item_idx.tolist() == [0, 1]
+
+
+def test_build_csr_matches_oracle_and_validates():
+    u, i, t, r = O.synth_log(50, 97, seed=5, mean_len=9, max_len=30)
+    perm = np.random.default_rng(0).permutation(len(u))
+    a = D.build_csr(u[perm], i[perm], t[perm], r[perm], 50)
+    b = O.build_csr(u[perm], i[perm], t[perm], r[perm], 50)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # datetime timestamps, ties broken by item_idx
+    ts = pd.to_datetime(["2020-01-02", "2020-01-01", "2020-01-01"]).to_numpy()
+    off, items, rew = D.build_csr([0, 0, 0], [5, 9, 7], ts, [1.0, 2.0, 3.0], 2)
+    assert off.tolist() == [0, 3, 3] and items.tolist() == [7, 9, 5] and rew.tolist() == [3.0, 2.0, 1.0]
+    with pytest.raises(ValueError):
+        D.build_csr([0, -1], [1, 2], [0, 1], [1.0, 1.0])
+    seen = D.sorted_seen(off, items)
+    assert seen.tolist() == [5, 7, 9]
+
+
+def test_synthetic_generator_is_shardable_and_deterministic():
+    off, items, rew = D.synth_log_device(3000, 500, seed=9, device="cpu")
+    o2, i2, r2 = D.synth_log_device(3000, 500, seed=9, device="cpu", user_lo=1000, user_hi=1700)
+    a, b = int(off[1000]), int(off[1700])
+    assert torch.equal(items[a:b], i2) and torch.equal(rew[a:b], r2) and torch.equal(off[1000:1701] - off[1000], o2)
+    lens = (off[1:] - off[:-1])
+    assert int(lens.min()) >= 5 and int(lens.max()) <= 200 and 30 < float(lens.float().mean()) < 60
+    assert int(items.min()) >= 0 and int(items.max()) < 500
+    assert set(np.round(rew.unique().numpy().astype(np.float64), 4).tolist()) <= {0.2, 0.4, 0.6, 0.8, 1.0}
+    o3, i3, _ = D.synth_log_device(3000, 500, seed=10, device="cpu")
+    assert not torch.equal(i3[:1000], items[:1000])
