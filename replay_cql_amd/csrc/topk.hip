@@ -18,6 +18,7 @@
 #define TK_CB_LARGE 4096    // 32 KiB: k <= 2048 (rare; lower occupancy)
 #define TK_MAX_K 2048
 #define TK_MAX_GROUPS 4096
+#define TK_SEEN_LDS 512      // seen-list entries kept in LDS per user
 
 __device__ __forceinline__ uint64_t make_key(float score, uint32_t id) {
   return ((uint64_t)f32_order_key(score) << 32) | (uint64_t)(~id);
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
   __shared__ uint32_t hist[256];
   __shared__ float scores[32];
   __shared__ uint64_t cand[TK_CB];
+  __shared__ int32_t seen_lds[TK_SEEN_LDS];
 
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int64_t u = blockIdx.x;
@@ -151,11 +153,7 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
     const int g = sl * 64 + lane;
     key[sl] = (g < ngroups) ? f32_order_key(tm_t[u * gstride + g]) : 0u;
   }
-  const int kk = k < ngroups ? k : ngroups;
 
-  // ---- radix select on the 32-bit keys: T = kk-th largest value, need_eq = how many of the == T keys are wanted ----
-  uint32_t T = 0;
-  int need = kk;
   // digits on which every key agrees need no histogram (scores of one user usually share the top byte; a shared
   // digit would also serialise all the LDS atomics on one word)
   uint32_t k_and = 0xFFFFFFFFu, k_or = 0u;
@@ -172,26 +170,43 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
     k_or |= __shfl_xor(k_or, off);
   }
   const uint32_t k_diff = k_and ^ k_or;
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    if (((k_diff >> shift) & 255u) == 0u) {
-      T |= k_and & (255u << shift);
-      continue;
-    }
-    for (int i = lane; i < 256; i += 64) hist[i] = 0;
-    __syncthreads();
+  unsigned long long done = 0;   // bit sl: this lane's slot sl has been re-scored
+  int remaining = ngroups;
+
+  // radix select over the NOT YET PROCESSED keys: T = want-th largest value among them, need_eq = how many of the
+  // == T keys (in group order) belong to the `want` best
+  auto select_round = [&](int want, uint32_t& T, int& need_eq) {
+    T = 0;
+    int need = want;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (((k_diff >> shift) & 255u) == 0u) {
+        T |= k_and & (255u << shift);
+        continue;
+      }
+      for (int i = lane; i < 256; i += 64) hist[i] = 0;
+      __syncthreads();
 #pragma unroll
-    for (int sl = 0; sl < KPL; ++sl) {
-      const int g = sl * 64 + lane;
-      const bool match = (g < ngroups) && ((shift == 24) || ((key[sl] >> (shift + 8)) == (T >> (shift + 8))));
-      if (match) atomicAdd(&hist[(key[sl] >> shift) & 255], 1u);
+      for (int sl = 0; sl < KPL; ++sl) {
+        const int g = sl * 64 + lane;
+        const bool match = (g < ngroups) && !((done >> sl) & 1ull) &&
+                           ((shift == 24) || ((key[sl] >> (shift + 8)) == (T >> (shift + 8))));
+        if (match) atomicAdd(&hist[(key[sl] >> shift) & 255], 1u);
+      }
+      __syncthreads();
+      int digit;
+      radix_pick(hist, lane, need, digit);
+      T |= (uint32_t)digit << shift;
+      __syncthreads();
     }
-    __syncthreads();
-    int digit;
-    radix_pick(hist, lane, need, digit);
-    T |= (uint32_t)digit << shift;
-    __syncthreads();
+    need_eq = need;
+  };
+
+  // the user's ascending seen list in LDS (binary-searched once per candidate); longer lists stay in global memory
+  const bool seen_in_lds = ns <= TK_SEEN_LDS;
+  if (seen_in_lds) {
+    for (int i = lane; i < ns; i += 64) seen_lds[i] = seen_items[so + i];
   }
-  const int need_eq = need;
+  __syncthreads();
 
   bf16x8 hf[KS];
 #pragma unroll
@@ -233,10 +248,10 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
             int lo = 0, hi = ns;
             while (lo < hi) {
               const int mid = (lo + hi) >> 1;
-              const int32_t v = seen_items[so + mid];
+              const int32_t v = seen_in_lds ? seen_lds[mid] : seen_items[so + mid];
               if (v < gid) lo = mid + 1; else hi = mid;
             }
-            if (lo < ns && seen_items[so + lo] == gid) valid = false;
+            if (lo < ns && (seen_in_lds ? seen_lds[lo] : seen_items[so + lo]) == gid) valid = false;
           }
           ck = make_key(sc, (uint32_t)gid);
         }
@@ -250,30 +265,59 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
     }
   };
 
-  // ---- round 1: the kk best groups by (max desc, group asc) ------------------------------------------------------
-  unsigned long long done = 0;   // bit sl: this lane's slot sl has been re-scored
-  int eq_base = 0;
+  // ---- rounds: the next k best unprocessed groups by (max desc, group asc), as long as one of them can still beat
+  //      the k-th best admissible candidate found so far (groups are visited in descending order of their bound) ----
+  uint64_t tau = 0;   // 0: fewer than k admissible candidates yet -> every group qualifies
+  while (remaining > 0) {
+    const uint32_t tau_hi = (uint32_t)(tau >> 32);
+    if (tau != 0) {   // cheap exit: the best unprocessed bound is already below the k-th best candidate
+      uint32_t rem_max = 0;
 #pragma unroll
-  for (int sl = 0; sl < KPL; ++sl) {
-    const int g = sl * 64 + lane;
-    const bool in = g < ngroups;
-    const bool eq = in && key[sl] == T;
-    const unsigned long long em = __ballot(eq);
-    const bool pick = in && (key[sl] > T || (eq && eq_base + __popcll(em & lt_mask) < need_eq));
-    eq_base += __popcll(em);
-    unsigned long long pm = __ballot(pick);
-    if (pick) done |= 1ull << sl;
-    while (pm) {
-      const int j = __ffsll((long long)pm) - 1;
-      pm &= pm - 1;
-      rescore(sl * 64 + j);
+      for (int sl = 0; sl < KPL; ++sl) {
+        const bool in = (sl * 64 + lane < ngroups) && !((done >> sl) & 1ull);
+        rem_max = (in && key[sl] > rem_max) ? key[sl] : rem_max;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(rem_max, off);
+        rem_max = o > rem_max ? o : rem_max;
+      }
+      if (rem_max < tau_hi) break;
     }
-  }
-
-  // ---- further rounds: only groups whose upper bound still beats the k-th best candidate ---------------------------
-  for (;;) {
+    const int want = k < remaining ? k : remaining;
+    uint32_t T;
+    int need_eq;
+    select_round(want, T, need_eq);
+    int eq_base = 0;
+    bool any = false;
+#pragma unroll
+    for (int sl = 0; sl < KPL; ++sl) {
+      const int g = sl * 64 + lane;
+      const bool in = (g < ngroups) && !((done >> sl) & 1ull);
+      const bool eq = in && key[sl] == T;
+      const unsigned long long em = __ballot(eq);
+      bool pick = in && (key[sl] > T || (eq && eq_base + __popcll(em & lt_mask) < need_eq));
+      eq_base += __popcll(em);
+      if (pick) {   // does the group's upper bound (its maximum, at its smallest item id) beat tau?
+        pick = key[sl] >= tau_hi;
+        if (pick && key[sl] == tau_hi && tau != 0) {
+          const int64_t c0 = (int64_t)g * tg * 32;
+          const uint32_t gid0 = (c0 < n_cand) ? (uint32_t)(item_ids ? item_ids[c0] : (int32_t)c0) : 0xFFFFFFFFu;
+          pick = (((uint64_t)tau_hi << 32) | (uint64_t)(~gid0)) > tau;
+        }
+      }
+      unsigned long long pm = __ballot(pick);
+      if (pick) done |= 1ull << sl;
+      any |= (pm != 0);
+      remaining -= __popcll(pm);
+      while (pm) {
+        const int j = __ffsll((long long)pm) - 1;
+        pm &= pm - 1;
+        rescore(sl * 64 + j);
+      }
+    }
+    if (!any) break;   // the best remaining groups cannot change the answer, nor can any worse one
     ncand = select_topk_inplace(cand, ncand, k, hist, lane);
-    uint64_t tau = 0;   // k-th best key so far (0: fewer than k admissible candidates yet -> everything qualifies)
     if (ncand >= k) {
       tau = ~0ull;
       for (int i = lane; i < ncand; i += 64) tau = cand[i] < tau ? cand[i] : tau;
@@ -283,28 +327,8 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
         tau = o < tau ? o : tau;
       }
     }
-    const uint32_t tau_hi = (uint32_t)(tau >> 32);
-    bool any = false;
-#pragma unroll
-    for (int sl = 0; sl < KPL; ++sl) {
-      const int g = sl * 64 + lane;
-      bool pick = (g < ngroups) && !((done >> sl) & 1ull) && key[sl] >= tau_hi;
-      if (pick && key[sl] == tau_hi) {   // tie on the score: the group's smallest item id decides
-        const int64_t c0 = (int64_t)g * tg * 32;
-        const uint32_t gid0 = (c0 < n_cand) ? (uint32_t)(item_ids ? item_ids[c0] : (int32_t)c0) : 0xFFFFFFFFu;
-        pick = (((uint64_t)tau_hi << 32) | (uint64_t)(~gid0)) > tau;
-      }
-      unsigned long long pm = __ballot(pick);
-      if (pick) done |= 1ull << sl;
-      any |= (pm != 0);
-      while (pm) {
-        const int j = __ffsll((long long)pm) - 1;
-        pm &= pm - 1;
-        rescore(sl * 64 + j);
-      }
-    }
-    if (!any) break;
   }
+  ncand = select_topk_inplace(cand, ncand, k, hist, lane);
 
   // ---- rank the survivors -------------------------------------------------------------------------------------------
   for (int i = lane; i < ncand; i += 64) {
