@@ -38,6 +38,7 @@ struct QCfg {
 #define NEG_INF (-__builtin_inff())
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) f32x4 lds_f4;
 typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
@@ -117,8 +118,20 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
       rf[g][s] = *reinterpret_cast<const bf16x8*>(a.res + row * D + 16 * s + 8 * h);
     rs[g] = BWD ? a.res_scalar[row] : 0.f;
   }
-  // the prologue's ordinary loads must have landed before LDS-DMA traffic starts (hipcc would otherwise drain the
-  // DMA queue at their first use inside the loop)
+  // The prologue's ordinary loads must be retired -- in hipcc's own bookkeeping -- before the loop: left alone, it
+  // places their counted waits (vmcnt(7) ... vmcnt(0)) at the first use INSIDE the loop, and since our LDS-DMA pieces
+  // share that counter every tile would drain the whole prefetch ring.  An empty asm that names each register forces
+  // the wait here.
+#pragma unroll
+  for (int g = 0; g < SPW; ++g) {
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      u32x4 t = __builtin_bit_cast(u32x4, rf[g][s]);
+      asm volatile("" : "+v"(t));
+      rf[g][s] = __builtin_bit_cast(bf16x8, t);
+    }
+    asm volatile("" : "+v"(rs[g]));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- per-mode state -------------------------------------------------------------------------------------
@@ -176,8 +189,8 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
     __builtin_amdgcn_s_barrier();   // everyone's pieces of this stage landed; everyone left stage-1's buffer
     if (stage + PD < nstage) issue(stage + PD);
 
-    const unsigned char* tile = smem + (stage % NBUF) * C::BUF_BYTES;
-    const float* sc = reinterpret_cast<const float*>(tile + C::STAGE_BYTES + wave * 256);
+    const lds_u8* tile = (const lds_u8*)smem + (stage % NBUF) * C::BUF_BYTES;
+    const lds_f4* sc = (const lds_f4*)(tile + C::STAGE_BYTES + wave * 256);
 
 #pragma unroll
     for (int it = 0; it < C::TI / 32; ++it) {
@@ -189,11 +202,11 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
       f32x16 sv;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 t4 = *reinterpret_cast<const float4*>(&sc[trow + 8 * q + 4 * h]);
-        sv[4 * q + 0] = t4.x;
-        sv[4 * q + 1] = t4.y;
-        sv[4 * q + 2] = t4.z;
-        sv[4 * q + 3] = t4.w;
+        const f32x4 t4 = sc[(trow + 8 * q + 4 * h) >> 2];
+        sv[4 * q + 0] = t4[0];
+        sv[4 * q + 1] = t4[1];
+        sv[4 * q + 2] = t4[2];
+        sv[4 * q + 3] = t4[3];
       }
       f32x16 acc[SPW];
 #pragma unroll
@@ -205,12 +218,21 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
           acc[g] = sv;
         }
       }
+      {
+        bf16x8 af[C::KS];
 #pragma unroll
-      for (int s = 0; s < C::KS; ++s) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(
-            &tile[(trow + r) * C::ROWB + swz2<D>(trow + r, 2 * s + h) * 16]);
+        for (int s = 0; s < C::KS; ++s)
+          af[s] = *(const lds_bf16x8*)(tile + (trow + r) * C::ROWB + swz2<D>(trow + r, 2 * s + h) * 16);
 #pragma unroll
-        for (int g = 0; g < SPW; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, rf[g][s], acc[g], 0, 0, 0);
+        for (int s = 0; s < C::KS; ++s) {
+#pragma unroll
+          for (int g = 0; g < SPW; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], rf[g][s], acc[g], 0, 0, 0);
+        }
+        // program order: every LDS read of the tile first, then the MFMA chain (hipcc otherwise re-sinks each read
+        // next to its MFMA and waits lgkmcnt(0) per k-step, exposing the LDS latency eight times per chain)
+        __builtin_amdgcn_sched_group_barrier(0x100, C::KS + 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, C::KS * SPW, 0);
       }
       if (partial) {   // rows past the end of the slice: -inf scores (forward) / zero probabilities (backward)
 #pragma unroll
@@ -270,6 +292,25 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
           }
         }
       } else {  // backward modes
+        // all transposed A-fragment reads of the tile are issued first: their LDS latency hides under the exp block
+        bf16x8 tf[FT][2];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int row = trow + 16 * s2 + 8 * jj + 4 * h + tr_q;
+              const int col = ft * 32 + tr_fsub + 4 * tr_p;
+              const lds_u8* p8 = tile + row * C::ROWB + swz2<D>(row, col >> 3) * 16 + (tr_p & 1) * 8;
+              const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p8);
+              tf[ft][s2][4 * jj + 0] = t4[0];
+              tf[ft][s2][4 * jj + 1] = t4[1];
+              tf[ft][s2][4 * jj + 2] = t4[2];
+              tf[ft][s2][4 * jj + 3] = t4[3];
+            }
+          }
+        }
         bf16x8 pf[SPW][2];
 #pragma unroll
         for (int g = 0; g < SPW; ++g) {
@@ -295,23 +336,16 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         for (int ft = 0; ft < FT; ++ft) {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 af;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-              const int row = trow + 16 * s2 + 8 * jj + 4 * h + tr_q;
-              const int col = ft * 32 + tr_fsub + 4 * tr_p;
-              const unsigned char* p8 = &tile[row * C::ROWB + swz2<D>(row, col >> 3) * 16 + (tr_p & 1) * 8];
-              const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p8);
-              af[4 * jj + 0] = t4[0];
-              af[4 * jj + 1] = t4[1];
-              af[4 * jj + 2] = t4[2];
-              af[4 * jj + 3] = t4[3];
-            }
 #pragma unroll
             for (int g = 0; g < SPW; ++g)
-              y[g][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf[g][s2], y[g][ft], 0, 0, 0);
+              y[g][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ft][s2], pf[g][s2], y[g][ft], 0, 0, 0);
           }
         }
+        // program order: the 4*FT transposed reads, then the exp / convert block (their latency hides under it),
+        // then the second MFMA chain back to back
+        __builtin_amdgcn_sched_group_barrier(0x100, FT * 4, 1);
+        __builtin_amdgcn_sched_group_barrier(0x402, 40 * SPW, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, FT * 2 * SPW, 1);
       }
     }
   }
@@ -365,6 +399,11 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
 // =============================================================================================================
 // split selection + launch
 // =============================================================================================================
+int qs_spw_fwd(int d) {
+  static const int v = qs_env_int("CQL_QS_SPW_FWD", QS_SPW_FWD);
+  return (v == 4 && d <= 128) ? 4 : 2;
+}
+
 QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows) {
   QSplit s;
   s.rblks = (n_res + 128 * spw - 1) / (128 * spw);
@@ -398,21 +437,19 @@ static void qs_launch_n(const QArgs& a, int64_t rblks, hipStream_t s) {
 
 template <int D, int SPW, int MODE>
 static void qs_launch_d(const QArgs& a, int64_t rblks, hipStream_t s) {
-  constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE);
-  if constexpr (BWD || D == 256) {
-    qs_launch_n<D, SPW, MODE, QS_NBUF, (D == 256 ? 1 : 2)>(a, rblks, s);
-  } else {
-    static const int minw = qs_env_int("CQL_QS_MINW", 2);
-    if (minw == 3) qs_launch_n<D, SPW, MODE, QS_NBUF, 3>(a, rblks, s);
-    else qs_launch_n<D, SPW, MODE, QS_NBUF, 2>(a, rblks, s);
-  }
+  qs_launch_n<D, SPW, MODE, QS_NBUF, (D == 256 ? 1 : 2)>(a, rblks, s);
 }
 
 template <int MODE, int SPW>
 static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
-  if (d == 64) qs_launch_d<64, SPW, MODE>(a, rblks, s);
-  else if (d == 128) qs_launch_d<128, SPW, MODE>(a, rblks, s);
-  else qs_launch_d<256, SPW, MODE>(a, rblks, s);
+  if constexpr (SPW == 4) {   // 128 owners per wave: d <= 128 only (register budget)
+    if (d == 64) qs_launch_d<64, SPW, MODE>(a, rblks, s);
+    else qs_launch_d<128, SPW, MODE>(a, rblks, s);
+  } else {
+    if (d == 64) qs_launch_d<64, SPW, MODE>(a, rblks, s);
+    else if (d == 128) qs_launch_d<128, SPW, MODE>(a, rblks, s);
+    else qs_launch_d<256, SPW, MODE>(a, rblks, s);
+  }
   return 0;
 }
 
@@ -421,9 +458,15 @@ int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
                                   CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE};
   CqlProfScope prof(phase_of[mode], s);
   switch (mode) {
-    case QM_LSE: return qs_launch_mode<QM_LSE, QS_SPW_FWD>(a, d, rblks, s);
-    case QM_ARGMAX: return qs_launch_mode<QM_ARGMAX, QS_SPW_FWD>(a, d, rblks, s);
-    case QM_TILEMAX: return qs_launch_mode<QM_TILEMAX, QS_SPW_FWD>(a, d, rblks, s);
+    case QM_LSE:
+      if (qs_spw_fwd(d) == 4) return qs_launch_mode<QM_LSE, 4>(a, d, rblks, s);
+      return qs_launch_mode<QM_LSE, 2>(a, d, rblks, s);
+    case QM_ARGMAX:
+      if (qs_spw_fwd(d) == 4) return qs_launch_mode<QM_ARGMAX, 4>(a, d, rblks, s);
+      return qs_launch_mode<QM_ARGMAX, 2>(a, d, rblks, s);
+    case QM_TILEMAX:
+      if (qs_spw_fwd(d) == 4) return qs_launch_mode<QM_TILEMAX, 4>(a, d, rblks, s);
+      return qs_launch_mode<QM_TILEMAX, 2>(a, d, rblks, s);
     case QM_BWD_DH: return qs_launch_mode<QM_BWD_DH, QS_SPW_BWD>(a, d, rblks, s);
     case QM_BWD_DE: return qs_launch_mode<QM_BWD_DE, QS_SPW_BWD>(a, d, rblks, s);
   }
@@ -577,7 +620,7 @@ static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" int64_t cqlrec_qhead_ws_bytes(int64_t rows, int64_t n_items, int32_t d) {
   (void)d;
-  const QSplit sp = qs_choose_split(n_items, rows, QS_SPW_FWD, QS_TI);
+  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI);
   return 3 * align256((int64_t)sp.nsplit * rows * 4) + 256;
 }
 
@@ -589,7 +632,7 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
   CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
   CQL_REQUIRE(mode == CQLREC_QHEAD_LSE || mode == CQLREC_QHEAD_ARGMAX, "qhead_fwd: bad mode %d", mode);
   CQL_REQUIRE(ws_bytes >= cqlrec_qhead_ws_bytes(rows, n_items, d), "qhead_fwd: workspace too small");
-  const QSplit sp = qs_choose_split(n_items, rows, QS_SPW_FWD, QS_TI);
+  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI);
   const int64_t seg = align256((int64_t)sp.nsplit * rows * 4);
   QArgs a = {};
   a.res = H_b;

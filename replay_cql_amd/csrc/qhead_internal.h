@@ -42,5 +42,6 @@ struct QSplit {
   int64_t rblks;
 };
 
+int qs_spw_fwd(int d);
 QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows);
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
