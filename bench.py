@@ -116,9 +116,7 @@ def main():
 
     def run(n, base):
         for i in range(n):
-            core.forward_backward(loss_buf[base + i: base + i + 1])
-            core.allreduce_grads()
-            core.apply_update()
+            core.train_step(loss_buf[base + i: base + i + 1])
 
     run(args.warmup, 0)
     barrier()

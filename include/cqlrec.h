@@ -74,6 +74,13 @@ int cqlrec_gather_pool_bwd(const float* dh0, const int64_t* offsets, const int32
                            const int32_t* ends, int32_t end_delta, int64_t n_states, int32_t L, int32_t d,
                            float* g_E_in, cqlrec_stream stream);
 int64_t cqlrec_gather_pool_bwd_ws_bytes(int64_t n_states, int32_t L, int32_t d);
+/* the same, split at the point where the gradient is needed: _prepare (pairs + sort) depends only on the sampled
+ * states, _apply (scale + segmented sum) on dh0.  The step driver runs _prepare on a side stream. */
+int cqlrec_gather_pool_bwd_prepare(const int64_t* offsets, const int32_t* items, const int32_t* users,
+                                   const int32_t* ends, int32_t end_delta, int64_t n_states, int32_t L, int32_t d,
+                                   int64_t n_items, void* ws, int64_t ws_bytes, cqlrec_stream stream);
+int cqlrec_gather_pool_bwd_apply(const float* dh0, int64_t n_states, int32_t L, int32_t d, int64_t n_items, void* ws,
+                                 int64_t ws_bytes, float* g_E_in, cqlrec_stream stream);
 int cqlrec_gather_pool_bwd_sorted(const float* dh0, const int64_t* offsets, const int32_t* items,
                                   const int32_t* users, const int32_t* ends, int32_t end_delta, int64_t n_states,
                                   int32_t L, int32_t d, int64_t n_items, void* ws, int64_t ws_bytes,
@@ -131,6 +138,16 @@ int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef,
                      int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
                      float scale, void* ws, int64_t ws_bytes, float* dH, float* g_E_out, float* g_b_out,
                      cqlrec_stream stream);
+
+/* the two halves of cqlrec_qhead_bwd, separately callable (a data-parallel caller all-reduces g_E_out/g_b_out
+ * while the state-side half still runs) */
+int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                           int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
+                           float scale, void* ws, int64_t ws_bytes, float* g_E_out, float* g_b_out,
+                           cqlrec_stream stream);
+int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                            int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
+                            float scale, void* ws, int64_t ws_bytes, float* dH, cqlrec_stream stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a7  Fused Adam + Polyak target + bf16 shadows over the flat buffer (S6).  Replaces optimizer.step()
@@ -201,6 +218,18 @@ int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* ctx /* [host] */, uint64_t
                               cqlrec_stream stream);
 /* Adam + target + shadows (+ zero grads). `step` is the same 0-based counter. */
 int cqlrec_train_step_update(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
+/* Finer-grained phases for overlapping the gradient all-reduce with compute (fwd_bwd == forward; backward_items;
+ * backward_rest.  update == update_range over [0, layout.total)):
+ *   forward         sample, state vectors, encoder, Q-head LSE/argmax, TD target, loss
+ *   backward_items  g_E_out, g_b_out                (elements [off_E_out, off_W1) of ctx->grads are final afterwards)
+ *   backward_rest   dH, encoder gradients, g_E_in   (the remaining elements are final afterwards)
+ *   update_range    Adam/Polyak/shadows/zero-grads over elements [lo, hi) (multiples of 4) */
+int cqlrec_train_step_forward(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,
+                              cqlrec_stream stream);
+int cqlrec_train_step_backward_items(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
+int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
+int cqlrec_train_step_update_range(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, int64_t lo, int64_t hi,
+                                   cqlrec_stream stream);
 
 /* Debug/inspection of the step's intermediates inside ctx->ws (device pointers; valid after fwd_bwd). */
 typedef struct cqlrec_train_views {

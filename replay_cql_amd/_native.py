@@ -64,6 +64,8 @@ SIGNATURES = {
     "cqlrec_gather_pool_fwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp, vp, vp]),
     "cqlrec_gather_pool_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp]),
     "cqlrec_gather_pool_bwd_ws_bytes": (i64, [i64, i32, i32]),
+    "cqlrec_gather_pool_bwd_prepare": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, i64, vp, i64, vp]),
+    "cqlrec_gather_pool_bwd_apply": (i32, [vp, i64, i32, i32, i64, vp, i64, vp, vp]),
     "cqlrec_gather_pool_bwd_sorted": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i64, vp, i64, vp, vp]),
     "cqlrec_linear_bf16": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
     "cqlrec_encoder_bwd_ws_bytes": (i64, [i64, i32]),
@@ -74,6 +76,8 @@ SIGNATURES = {
     "cqlrec_td_loss": (i32, [vp, vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp]),
     "cqlrec_qhead_bwd_ws_bytes": (i64, [i64, i64, i32]),
     "cqlrec_qhead_bwd": (i32, [vp, vp, vp, vp, i64, vp, vp, i64, i32, f32, vp, i64, vp, vp, vp, vp]),
+    "cqlrec_qhead_bwd_items": (i32, [vp, vp, vp, vp, i64, vp, vp, i64, i32, f32, vp, i64, vp, vp, vp]),
+    "cqlrec_qhead_bwd_states": (i32, [vp, vp, vp, vp, i64, vp, vp, i64, i32, f32, vp, i64, vp, vp]),
     "cqlrec_adam_ema": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i32, vp]),
     "cqlrec_cast_bf16": (i32, [vp, vp, i64, vp]),
     "cqlrec_topk_ws_bytes": (i64, [i64, i64, i32, i32]),
@@ -81,6 +85,10 @@ SIGNATURES = {
     "cqlrec_train_ws_bytes": (i64, [i32, i64, i32, i32]),
     "cqlrec_train_step_fwd_bwd": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
     "cqlrec_train_step_update": (i32, [C.POINTER(TrainCtx), u64, vp]),
+    "cqlrec_train_step_forward": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
+    "cqlrec_train_step_backward_items": (i32, [C.POINTER(TrainCtx), u64, vp]),
+    "cqlrec_train_step_backward_rest": (i32, [C.POINTER(TrainCtx), u64, vp]),
+    "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),
     "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), C.POINTER(TrainViews)]),
     "cqlrec_prof_enable": (i32, [i32]),
     "cqlrec_prof_read": (i32, [C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -170,14 +170,45 @@ class CQLCore:
             from .dist import allreduce_sum_
             allreduce_sum_(self.grads, self.pg)
 
-    def train(self, n_steps: int) -> torch.Tensor:
+    def train_step(self, loss_out: Optional[torch.Tensor] = None, phased: Optional[bool] = None) -> None:
+        """One full CQL step.  Single GPU: fused fwd_bwd + update.  Data parallel (or phased=True): the step runs in
+        phases so that the all-reduce of the catalogue-side gradients (E_out, b_out: half of the bytes) overlaps the
+        state-side backward, and Adam on that half overlaps the all-reduce of the rest (E_in + encoder)."""
+        phased = (self.world > 1) if phased is None else phased
+        if not phased:
+            self.forward_backward(loss_out)
+            self.allreduce_grads()
+            self.apply_update()
+            return
+        c, s, lay = self._train_ctx(), _stream(), self.layout
+        lo_a, hi_a, total = int(lay.off_E_out), int(lay.off_W1), int(lay.total)
+        N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(loss_out), s), "train_step_forward")
+        N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, s), "train_step_backward_items")
+        work_a = self._allreduce_async(self.grads[lo_a:hi_a])
+        N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
+        work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
+        if work_a is not None:
+            work_a.wait()          # stream-side wait (RCCL): no host block
+        N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, lo_a, hi_a, s), "update_range")
+        for w in work_b:
+            if w is not None:
+                w.wait()
+        N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, 0, lo_a, s), "update_range")
+        N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, hi_a, total, s), "update_range")
+        self.step += 1
+
+    def _allreduce_async(self, t: torch.Tensor):
+        if self.world <= 1:
+            return None
+        import torch.distributed as dist
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def train(self, n_steps: int, phased: Optional[bool] = None) -> torch.Tensor:
         """n_steps CQL steps; returns the per-step (rank-local share of the) loss as a device tensor -- no host sync
         inside the loop (cf. loss.item() per step at replay/models/base_torch_rec.py:39)."""
         losses = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=self.device)
         for i in range(n_steps):
-            self.forward_backward(losses[i:i + 1])
-            self.allreduce_grads()
-            self.apply_update()
+            self.train_step(losses[i:i + 1], phased)
         if self.world > 1 and n_steps > 0:
             import torch.distributed as dist
             dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=self.pg)

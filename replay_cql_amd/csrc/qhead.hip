@@ -676,76 +676,97 @@ extern "C" int64_t cqlrec_qhead_bwd_ws_bytes(int64_t batch, int64_t n_items, int
   return (a1 > a2 ? a1 : a2) + 256;
 }
 
-extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
-                                int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
-                                float scale, void* ws, int64_t ws_bytes, float* dH, float* g_E_out, float* g_b_out,
-                                cqlrec_stream stream) {
-  CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && dH && g_E_out && g_b_out, "qhead_bwd: NULL pointer");
-  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_bwd: d=%d unsupported", d);
-  CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
-  CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd: workspace too small");
+// dH only (owner = states, streamed = items)
+extern "C" int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                                       int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                                       int32_t d, float scale, void* ws, int64_t ws_bytes, float* dH,
+                                       cqlrec_stream stream) {
+  CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && dH, "qhead_bwd_states: NULL pointer");
+  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_bwd_states: d=%d unsupported", d);
+  CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd_states: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
+  CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd_states: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  // ---- dH: owner = states, streamed = items ----
-  {
-    const QSplit sp = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI);
-    QArgs a = {};
-    a.res = H_b;
-    a.n_res = batch;
-    a.str = E_out_b;
-    a.n_str = n_items;
-    a.str_scalar = b_out;
-    a.res_scalar = nlse2;
-    a.nsplit = sp.nsplit;
-    a.split_rows = sp.split_rows;
-    a.slab = (float*)ws;
-    a.tg = 1;
-    qs_launch(QM_BWD_DH, a, d, sp.rblks, s);
-    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
-    const int64_t n4 = batch * (d / 4);
-    dim3 grid(cql_ceil_div(n4, 256)), block(256);
+  const QSplit sp = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI);
+  QArgs a = {};
+  a.res = H_b;
+  a.n_res = batch;
+  a.str = E_out_b;
+  a.n_str = n_items;
+  a.str_scalar = b_out;
+  a.res_scalar = nlse2;
+  a.nsplit = sp.nsplit;
+  a.split_rows = sp.split_rows;
+  a.slab = (float*)ws;
+  a.tg = 1;
+  qs_launch(QM_BWD_DH, a, d, sp.rblks, s);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  const int64_t n4 = batch * (d / 4);
+  dim3 grid(cql_ceil_div(n4, 256)), block(256);
 #define RED_DH(DD)                                                                                                  \
   hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, (const float*)nullptr, a.nsplit, batch, \
                      scale, coef, act, E_out_b, dH, (float*)nullptr)
-    if (d == 64) RED_DH(64); else if (d == 128) RED_DH(128); else RED_DH(256);
+  if (d == 64) RED_DH(64); else if (d == 128) RED_DH(128); else RED_DH(256);
 #undef RED_DH
+  CQL_LAUNCH_CHECK("qhead_bwd_states");
+  return CQLREC_OK;
+}
+
+// g_E_out / g_b_out only (owner = items, streamed = states)
+extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                                      int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                                      int32_t d, float scale, void* ws, int64_t ws_bytes, float* g_E_out,
+                                      float* g_b_out, cqlrec_stream stream) {
+  CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && g_E_out && g_b_out, "qhead_bwd_items: NULL pointer");
+  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_bwd_items: d=%d unsupported", d);
+  CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd_items: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
+  CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd_items: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const QSplit sp = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI);
+  QArgs a = {};
+  a.res = E_out_b;
+  a.n_res = n_items;
+  a.str = H_b;
+  a.n_str = batch;
+  a.str_scalar = nlse2;
+  a.res_scalar = b_out;
+  a.nsplit = sp.nsplit;
+  a.split_rows = sp.split_rows;
+  a.slab = (float*)ws;
+  a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * n_items * d * 4));
+  a.tg = 1;
+  const bool direct = (sp.nsplit == 1);
+  if (direct) {   // one slice: the kernel scales and writes g_E_out / g_b_out itself
+    a.out = g_E_out;
+    a.out_cs = g_b_out;
+    a.scale = scale;
   }
-  // ---- dE_out / db_out: owner = items, streamed = states ----
-  {
-    const QSplit sp = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI);
-    QArgs a = {};
-    a.res = E_out_b;
-    a.n_res = n_items;
-    a.str = H_b;
-    a.n_str = batch;
-    a.str_scalar = nlse2;
-    a.res_scalar = b_out;
-    a.nsplit = sp.nsplit;
-    a.split_rows = sp.split_rows;
-    a.slab = (float*)ws;
-    a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * n_items * d * 4));
-    a.tg = 1;
-    const bool direct = (sp.nsplit == 1);
-    if (direct) {   // one slice: the kernel scales and writes g_E_out / g_b_out itself
-      a.out = g_E_out;
-      a.out_cs = g_b_out;
-      a.scale = scale;
-    }
-    qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
-    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  dim3 block(256);
+  if (!direct) {
     const int64_t n4 = n_items * (d / 4);
-    dim3 grid(cql_ceil_div(n4, 256)), block(256);
-    if (!direct) {
+    dim3 grid(cql_ceil_div(n4, 256));
 #define RED_DE(DD)                                                                                              \
   hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, a.slab_cs, a.nsplit, n_items, scale, \
                      (const float*)nullptr, (const int32_t*)nullptr, (const uint16_t*)nullptr, g_E_out, g_b_out)
     if (d == 64) RED_DE(64); else if (d == 128) RED_DE(128); else RED_DE(256);
 #undef RED_DE
-    }
-    dim3 g2(cql_ceil_div(batch, 4));
-#define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
-    if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);
-#undef SP_DE
   }
-  CQL_LAUNCH_CHECK("qhead_bwd");
+  dim3 g2(cql_ceil_div(batch, 4));
+#define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
+  if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);
+#undef SP_DE
+  CQL_LAUNCH_CHECK("qhead_bwd_items");
   return CQLREC_OK;
+}
+
+extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                                int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
+                                float scale, void* ws, int64_t ws_bytes, float* dH, float* g_E_out, float* g_b_out,
+                                cqlrec_stream stream) {
+  int rc = cqlrec_qhead_bwd_items(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
+                                  g_b_out, stream);
+  if (rc != CQLREC_OK) return rc;
+  return cqlrec_qhead_bwd_states(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, dH,
+                                 stream);
 }

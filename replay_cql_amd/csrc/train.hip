@@ -90,70 +90,154 @@ extern "C" int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t
     if (rc__ != CQLREC_OK) return rc__; \
   } while (0)
 
-extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
+namespace {
+// side stream for the part of the gather backward that depends only on the sampled batch (pairs + radix sort): it
+// runs underneath the Q-head kernels.  Fork/join through events, so the structure stays capturable in a hipGraph.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t forked = nullptr, joined = nullptr;
+  bool ok = false;
+};
+SideStream& side_stream() {
+  static SideStream ss;
+  if (!ss.ok) {
+    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.forked, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.joined, hipEventDisableTiming) == hipSuccess;
+  }
+  return ss;
+}
+
+struct StepPtrs {
+  const uint16_t *Ein_b, *Eout_b, *W1_b, *W2_b, *tEin_b, *tEout_b, *tW1_b, *tW2_b;
+  const float *b_out, *b1, *b2, *tb_out, *tb1, *tb2;
+};
+StepPtrs step_ptrs(const cqlrec_train_ctx* c) {
+  const cqlrec_layout& L = c->layout;
+  StepPtrs p;
+  p.Ein_b = c->theta_b + L.off_E_in;   p.Eout_b = c->theta_b + L.off_E_out;
+  p.W1_b = c->theta_b + L.off_W1;      p.W2_b = c->theta_b + L.off_W2;
+  p.b_out = c->theta + L.off_b_out;    p.b1 = c->theta + L.off_b1;   p.b2 = c->theta + L.off_b2;
+  p.tEin_b = c->target_b + L.off_E_in; p.tEout_b = c->target_b + L.off_E_out;
+  p.tW1_b = c->target_b + L.off_W1;    p.tW2_b = c->target_b + L.off_W2;
+  p.tb_out = c->target + L.off_b_out;  p.tb1 = c->target + L.off_b1; p.tb2 = c->target + L.off_b2;
+  return p;
+}
+}  // namespace
+
+// phase 1: sample + forward + loss (+ the sort for the gather backward, forked onto the side stream)
+extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
                                          cqlrec_stream stream) {
   CQL_TRY(check_ctx(c));
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d, W = c->window;
   const int64_t N = L.n_items;
   StepWs w = carve_step(c->ws, B, N, d, W);
+  const StepPtrs p = step_ptrs(c);
   const int64_t Bd = (int64_t)B * d;
+  hipStream_t s = (hipStream_t)stream;
 
-  const uint16_t* Ein_b = c->theta_b + L.off_E_in;
-  const uint16_t* Eout_b = c->theta_b + L.off_E_out;
-  const uint16_t* W1_b = c->theta_b + L.off_W1;
-  const uint16_t* W2_b = c->theta_b + L.off_W2;
-  const float* b_out = c->theta + L.off_b_out;
-  const float* b1 = c->theta + L.off_b1;
-  const float* b2 = c->theta + L.off_b2;
-  const uint16_t* tEin_b = c->target_b + L.off_E_in;
-  const uint16_t* tEout_b = c->target_b + L.off_E_out;
-  const uint16_t* tW1_b = c->target_b + L.off_W1;
-  const uint16_t* tW2_b = c->target_b + L.off_W2;
-  const float* tb_out = c->target + L.off_b_out;
-  const float* tb1 = c->target + L.off_b1;
-  const float* tb2 = c->target + L.off_b2;
-
-  // 1. transitions of this rank's slots of the global step
+  // transitions of this rank's slots of the global step
   CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
                                     (uint64_t)c->rank * (uint64_t)B, B, w.users, w.tpos, w.act, w.rew, w.done, stream));
-  // 2. state vectors: s, s' under theta; s' under the target net
-  CQL_TRY(cqlrec_gather_pool_fwd(Ein_b, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, w.h0_s, w.h0b, nullptr, stream));
-  CQL_TRY(cqlrec_gather_pool_fwd(Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, stream));
-  CQL_TRY(cqlrec_gather_pool_fwd(tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, stream));
-  // 3. encoder
-  CQL_TRY(cqlrec_linear_bf16(w.h0b, W1_b, b1, 2 * (int64_t)B, d, 1, nullptr, w.zb, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.zb, W2_b, b2, 2 * (int64_t)B, d, 0, nullptr, w.hb, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.h0b_t, tW1_b, tb1, B, d, 1, nullptr, w.zb_t, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.zb_t, tW2_b, tb2, B, d, 0, nullptr, w.hb_t, stream));
-  // 4. Q-head: logsumexp over the catalog for s, argmax for s'
-  CQL_TRY(cqlrec_qhead_fwd(w.hb, B, Eout_b, b_out, N, d, CQLREC_QHEAD_LSE, w.ws_q, w.ws_q_bytes, w.lse, nullptr, w.nlse2, stream));
-  CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, Eout_b, b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q, w.ws_q_bytes, w.maxv, w.a_star, nullptr, stream));
-  CQL_TRY(cqlrec_gather_dot(w.hb, Eout_b, b_out, w.act, B, d, w.q_a, stream));
-  CQL_TRY(cqlrec_gather_dot(w.hb_t, tEout_b, tb_out, w.a_star, B, d, w.q_targ, stream));
-  // 5. loss + dQ coefficients
+  SideStream& ss = side_stream();
+  if (ss.ok) {
+    if (hipEventRecord(ss.forked, s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.forked, 0) != hipSuccess) ss.ok = false;
+  }
+  if (ss.ok) {
+    CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
+                                           (cqlrec_stream)ss.s));
+    if (hipEventRecord(ss.joined, ss.s) != hipSuccess) {
+      cql_set_error("train_step_forward: hipEventRecord failed");
+      return CQLREC_ERR_HIP;
+    }
+  } else {
+    CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
+                                           stream));
+  }
+  // state vectors: s, s' under theta; s' under the target net
+  CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, w.h0_s, w.h0b, nullptr, stream));
+  CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, stream));
+  CQL_TRY(cqlrec_gather_pool_fwd(p.tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, stream));
+  // encoder
+  CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, 2 * (int64_t)B, d, 1, nullptr, w.zb, stream));
+  CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, 2 * (int64_t)B, d, 0, nullptr, w.hb, stream));
+  CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, stream));
+  CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, stream));
+  // Q-head: logsumexp over the catalog for s, argmax for s'
+  CQL_TRY(cqlrec_qhead_fwd(w.hb, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_LSE, w.ws_q, w.ws_q_bytes, w.lse, nullptr, w.nlse2, stream));
+  CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q, w.ws_q_bytes, w.maxv, w.a_star, nullptr, stream));
+  CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
+  CQL_TRY(cqlrec_gather_dot(w.hb_t, p.tEout_b, p.tb_out, w.a_star, B, d, w.q_targ, stream));
+  // loss + dQ coefficients
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
   CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, c->gamma, c->alpha, inv_batch, w.coef, w.y,
                          loss_out ? loss_out : w.loss, stream));
-  // 6. backward
-  CQL_TRY(cqlrec_qhead_bwd(w.hb, w.nlse2, w.coef, w.act, B, Eout_b, b_out, N, d, c->alpha * inv_batch, w.ws_qb,
-                           w.ws_qb_bytes, w.dH, c->grads + L.off_E_out, c->grads + L.off_b_out, stream));
-  CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, W1_b, W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
-                             c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
-  CQL_TRY(cqlrec_gather_pool_bwd_sorted(w.dh0, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb,
-                                        w.ws_gb_bytes, c->grads + L.off_E_in, stream));
   return CQLREC_OK;
 }
 
-extern "C" int cqlrec_train_step_update(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+// phase 2: the catalogue-side gradients g_E_out, g_b_out (half of the gradient bytes; a data-parallel caller starts
+// their all-reduce while phase 3 runs)
+extern "C" int cqlrec_train_step_backward_items(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  (void)step;
   CQL_TRY(check_ctx(c));
+  const cqlrec_layout& L = c->layout;
+  const int32_t B = c->batch, d = L.d;
+  StepWs w = carve_step(c->ws, B, L.n_items, d, c->window);
+  const StepPtrs p = step_ptrs(c);
+  const float inv_batch = 1.0f / ((float)B * (float)c->world);
+  return cqlrec_qhead_bwd_items(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
+                                w.ws_qb, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out, stream);
+}
+
+// phase 3: dH, encoder backward, window-gather backward (joins the side stream)
+extern "C" int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  (void)step;
+  CQL_TRY(check_ctx(c));
+  const cqlrec_layout& L = c->layout;
+  const int32_t B = c->batch, d = L.d, W = c->window;
+  const int64_t N = L.n_items;
+  StepWs w = carve_step(c->ws, B, N, d, W);
+  const StepPtrs p = step_ptrs(c);
+  const float inv_batch = 1.0f / ((float)B * (float)c->world);
+  CQL_TRY(cqlrec_qhead_bwd_states(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, N, d, c->alpha * inv_batch, w.ws_qb,
+                                  w.ws_qb_bytes, w.dH, stream));
+  CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
+                             c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
+  SideStream& ss = side_stream();
+  if (ss.ok && hipStreamWaitEvent((hipStream_t)stream, ss.joined, 0) != hipSuccess) {
+    cql_set_error("train_step_backward_rest: hipStreamWaitEvent failed");
+    return CQLREC_ERR_HIP;
+  }
+  CQL_TRY(cqlrec_gather_pool_bwd_apply(w.dh0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, c->grads + L.off_E_in, stream));
+  return CQLREC_OK;
+}
+
+extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
+                                         cqlrec_stream stream) {
+  CQL_TRY(cqlrec_train_step_forward(c, step, loss_out, stream));
+  CQL_TRY(cqlrec_train_step_backward_items(c, step, stream));
+  return cqlrec_train_step_backward_rest(c, step, stream);
+}
+
+// Adam + target + shadows (+ zero grads) over elements [lo, hi) of the flat buffers (multiples of 4)
+extern "C" int cqlrec_train_step_update_range(const cqlrec_train_ctx* c, uint64_t step, int64_t lo, int64_t hi,
+                                              cqlrec_stream stream) {
+  CQL_TRY(check_ctx(c));
+  CQL_REQUIRE(lo >= 0 && hi <= c->layout.total && lo < hi && lo % 4 == 0 && hi % 4 == 0,
+              "train_step_update_range: bad range [%lld, %lld)", (long long)lo, (long long)hi);
   const double t = (double)(step + 1);
   const double bc1 = 1.0 - pow((double)c->beta1, t);
   const double bc2 = 1.0 - pow((double)c->beta2, t);
   const float step_size = (float)((double)c->lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
-  return cqlrec_adam_ema(c->theta, c->grads, c->adam_m, c->adam_v, c->target, c->theta_b, c->target_b, c->layout.total,
-                         step_size, sqrt_bc2, c->beta1, c->beta2, c->eps, c->tau, 1, stream);
+  return cqlrec_adam_ema(c->theta + lo, c->grads + lo, c->adam_m + lo, c->adam_v + lo, c->target + lo, c->theta_b + lo,
+                         c->target_b + lo, hi - lo, step_size, sqrt_bc2, c->beta1, c->beta2, c->eps, c->tau, 1, stream);
+}
+
+extern "C" int cqlrec_train_step_update(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  CQL_TRY(check_ctx(c));
+  return cqlrec_train_step_update_range(c, step, 0, c->layout.total, stream);
 }
 
 extern "C" int cqlrec_train_views_get(const cqlrec_train_ctx* c, cqlrec_train_views* out) {

@@ -128,3 +128,18 @@ def test_core_predict_matches_oracle():
     pi = np.random.default_rng(0).integers(0, Nn, U).astype(np.int32)
     ps = core.pair_scores(hb, torch.as_tensor(pi).to(DEV)).cpu().numpy()
     np.testing.assert_allclose(ps, Q[np.arange(U), pi], atol=2e-3)
+
+
+def test_phased_step_equals_fused_step():
+    """the data-parallel phase split (forward / backward_items / backward_rest / update_range x3, side-stream sort)
+    computes the same step as the fused driver (up to float-atomic order in the gather backward)."""
+    m, core_a, (off, items, rew) = _make(300, 1000, 128, 256, 8)
+    _, core_b, _ = _make(300, 1000, 128, 256, 8)
+    la = core_a.train(5, phased=False).cpu().numpy()
+    lb = core_b.train(5, phased=True).cpu().numpy()
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    assert core_a.step == core_b.step == 5
+    torch.testing.assert_close(core_a.theta, core_b.theta, rtol=0, atol=2e-6)
+    torch.testing.assert_close(core_a.target, core_b.target, rtol=0, atol=2e-6)
+    assert torch.count_nonzero(core_b.grads).item() == 0
+    assert torch.equal(core_b.theta_b.float(), core_b.theta.to(torch.bfloat16).float())
