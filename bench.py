@@ -86,13 +86,20 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # rehearsal knobs (not used by the driver): several ranks on ONE GPU with gloo, to exercise the N > 1 code path
+    backend = os.environ.get("CQL_DIST_BACKEND", "nccl")
+    if os.environ.get("CQL_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from replay_cql_amd import _native as N

@@ -343,79 +343,76 @@ extern "C" int cqlrec_linear_bf16(const uint16_t* X_b, const uint16_t* W_b, cons
 }
 
 // =============================================================================================================
-// encoder backward, fp32 VALU on LDS tiles (d x d weights; ~1 % of the step).
+// encoder backward in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32: one f32 per lane for A and B, result
+// bitwise a k-ordered fmaf chain -- cdna_hip_programming.md section 3 "FP32-input MFMA"); d x d weights, ~1 % of the step
 //   dA1 = (dH W2_b) * [z_b > 0];  dh0 = dA1 W1_b;  gW2 = dH^T z_b;  gW1 = dA1^T h0_b;  gb2 = colsum dH;  gb1 = colsum dA1
 // =============================================================================================================
+// block = 32 rows (b) x all D columns: wave w owns columns [32w*.., ...) in tiles of 32; dH / dA1 tiles live in LDS
+// (row stride D+1 floats: the A operand is read column-wise, 32 lanes x 32 rows).
 template <int D>
 __global__ __launch_bounds__(256) void enc_bwd_dx_kernel(const float* __restrict__ dH, const uint16_t* __restrict__ zb,
                                                          const uint16_t* __restrict__ W1b,
                                                          const uint16_t* __restrict__ W2b, int64_t rows,
                                                          float* __restrict__ dA1, float* __restrict__ dh0) {
-  constexpr int RG = 256 / D;      // row groups
-  constexpr int RPT = 32 / RG;     // rows per thread
-  __shared__ __attribute__((aligned(16))) float tile[2][32][D];
-  const int t = threadIdx.x;
+  constexpr int LD = D + 1;
+  constexpr int NT = D / 32;                 // column tiles
+  __shared__ float tile[2][32 * LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 32;
-  for (int i = t; i < 32 * D / 4; i += 256) {
-    const int rr = i / (D / 4), cc = i % (D / 4);
-    float4 v = make_float4(0, 0, 0, 0);
-    if (m0 + rr < rows) v = *reinterpret_cast<const float4*>(dH + (m0 + rr) * D + cc * 4);
-    *reinterpret_cast<float4*>(&tile[0][rr][cc * 4]) = v;
+  for (int i = t; i < 32 * D; i += 256) {
+    const int rr = i / D, cc = i % D;
+    tile[0][rr * LD + cc] = (m0 + rr < rows) ? dH[(m0 + rr) * D + cc] : 0.f;
   }
   __syncthreads();
-  const int col = t % D, rbase = (t / D) * RPT;
-  float acc[RPT];
+  // ---- dA1 tile = dH W2_b, masked by the relu ----
+  for (int nt = wave; nt < NT; nt += 4) {
+    f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
-  for (int o = 0; o < D; o += 4) {
-    float w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = bf16_bits_to_f32(W2b[(int64_t)(o + q) * D + col]);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const float4 g = *reinterpret_cast<const float4*>(&tile[0][rbase + r][o]);
-      acc[r] = fmaf(g.x, w[0], acc[r]);
-      acc[r] = fmaf(g.y, w[1], acc[r]);
-      acc[r] = fmaf(g.z, w[2], acc[r]);
-      acc[r] = fmaf(g.w, w[3], acc[r]);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < D / 2; ++s) {
+      const int o = 2 * s + h;
+      const float a = tile[0][r * LD + o];                                     // A[b = r][o]
+      const float bv = bf16_bits_to_f32(W2b[(int64_t)o * D + nt * 32 + r]);    // B[o][k = nt*32 + r]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
     }
-  }
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const int64_t m = m0 + rbase + r;
-    float v = 0.f;
-    if (m < rows) {
-      const float z = bf16_bits_to_f32(zb[m * D + col]);
-      v = (z > 0.f) ? acc[r] : 0.f;
-      dA1[m * D + col] = v;
+    for (int i = 0; i < 16; ++i) {
+      const int rr = mfma_row(i, h), col = nt * 32 + r;
+      const int64_t m = m0 + rr;
+      float v = 0.f;
+      if (m < rows) {
+        const float z = bf16_bits_to_f32(zb[m * D + col]);
+        v = (z > 0.f) ? acc[i] : 0.f;
+        dA1[m * D + col] = v;
+      }
+      tile[1][rr * LD + col] = v;
     }
-    tile[1][rbase + r][col] = v;
   }
   __syncthreads();
+  // ---- dh0 tile = dA1 W1_b ----
+  for (int nt = wave; nt < NT; nt += 4) {
+    f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
-  for (int k = 0; k < D; k += 4) {
-    float w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = bf16_bits_to_f32(W1b[(int64_t)(k + q) * D + col]);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      const float4 g = *reinterpret_cast<const float4*>(&tile[1][rbase + r][k]);
-      acc[r] = fmaf(g.x, w[0], acc[r]);
-      acc[r] = fmaf(g.y, w[1], acc[r]);
-      acc[r] = fmaf(g.z, w[2], acc[r]);
-      acc[r] = fmaf(g.w, w[3], acc[r]);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < D / 2; ++s) {
+      const int k = 2 * s + h;
+      const float a = tile[1][r * LD + k];
+      const float bv = bf16_bits_to_f32(W1b[(int64_t)k * D + nt * 32 + r]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
     }
-  }
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    const int64_t m = m0 + rbase + r;
-    if (m < rows) dh0[m * D + col] = acc[r];
+    for (int i = 0; i < 16; ++i) {
+      const int64_t m = m0 + mfma_row(i, h);
+      if (m < rows) dh0[m * D + nt * 32 + r] = acc[i];
+    }
   }
 }
 
 // partial dW over a chunk of ENC_CH rows: slab[pair][chunk][o][i] = sum_{b in chunk} G[b][o] X[b][i];
-// grid = (D/64 * D/64, nchunk, 2).  Threads own 4x4 outputs of a 64x64 tile.
+// one wave per 32x32 output tile and chunk: grid = (D/32 * D/32 / 4, nchunk, 2), 4 tiles per block.
 #define ENC_CH 128
 template <int D>
 __global__ __launch_bounds__(256) void enc_bwd_dw_kernel(const float* __restrict__ dH, const float* __restrict__ dA1,
@@ -423,56 +420,35 @@ __global__ __launch_bounds__(256) void enc_bwd_dw_kernel(const float* __restrict
                                                          const uint16_t* __restrict__ h0b, int64_t rows,
                                                          float* __restrict__ slab_w, float* __restrict__ slab_b,
                                                          int nchunk) {
-  __shared__ __attribute__((aligned(16))) float Gs[32][64];
-  __shared__ __attribute__((aligned(16))) float Xs[32][64];
+  constexpr int NT = D / 32;
   const int pair = blockIdx.z, chunk = blockIdx.y;
-  const int ot = blockIdx.x / (D / 64), it = blockIdx.x % (D / 64);
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int tile_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ot = tile_id / NT, it = tile_id % NT;
   const float* G = pair == 0 ? dH : dA1;
   const uint16_t* X = pair == 0 ? zb : h0b;
-  const int t = threadIdx.x, to = t / 16, ti = t % 16;
-  float acc[4][4];
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
   const int64_t b0 = (int64_t)chunk * ENC_CH;
-  for (int sub = 0; sub < ENC_CH; sub += 32) {
-    __syncthreads();
-    for (int i = t; i < 32 * 16; i += 256) {
-      const int rr = i / 16, cc = i % 16;
-      const int64_t m = b0 + sub + rr;
-      float4 g = make_float4(0, 0, 0, 0), x = make_float4(0, 0, 0, 0);
-      if (m < rows) {
-        g = *reinterpret_cast<const float4*>(G + m * D + ot * 64 + cc * 4);
-        const uint2 xb = *reinterpret_cast<const uint2*>(X + m * D + it * 64 + cc * 4);
-        x = make_float4(__uint_as_float(xb.x << 16), __uint_as_float(xb.x & 0xFFFF0000u),
-                        __uint_as_float(xb.y << 16), __uint_as_float(xb.y & 0xFFFF0000u));
-      }
-      *reinterpret_cast<float4*>(&Gs[rr][cc * 4]) = g;
-      *reinterpret_cast<float4*>(&Xs[rr][cc * 4]) = x;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int rr = 0; rr < 32; ++rr) {
-      const float4 g = *reinterpret_cast<const float4*>(&Gs[rr][to * 4]);
-      const float4 x = *reinterpret_cast<const float4*>(&Xs[rr][ti * 4]);
-      const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w};
+  f32x16 acc;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(gv[a], xv[b], acc[a][b]);
-        bs[a] += gv[a];
-      }
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bs = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < ENC_CH / 2; ++s) {
+    const int64_t m = b0 + 2 * s + h;
+    float a = 0.f, bv = 0.f;
+    if (m < rows) {
+      a = G[m * D + ot * 32 + r];                            // A[o = r][b]  (row m of G: coalesced across r)
+      bv = bf16_bits_to_f32(X[m * D + it * 32 + r]);         // B[b][i = r]
     }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    bs += a;
   }
   float* sw = slab_w + ((int64_t)pair * nchunk + chunk) * D * D;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int o = ot * 64 + to * 4 + a;
-    *reinterpret_cast<float4*>(sw + (int64_t)o * D + it * 64 + ti * 4) =
-        make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
-    if (it == 0 && ti == 0) slab_b[((int64_t)pair * nchunk + chunk) * D + o] = bs[a];
+  for (int i = 0; i < 16; ++i) sw[(int64_t)(ot * 32 + mfma_row(i, h)) * D + it * 32 + r] = acc[i];
+  if (it == 0) {
+    bs += __shfl_xor(bs, 32);
+    if (h == 0) slab_b[((int64_t)pair * nchunk + chunk) * D + ot * 32 + r] = bs;
   }
 }
 
@@ -485,6 +461,7 @@ __global__ void enc_bwd_reduce_kernel(const float* __restrict__ slab_w, const fl
   float* gb = pair == 0 ? gb2 : gb1;
   if (idx < D * D) {
     float s = 0.f;
+#pragma unroll 8
     for (int c = 0; c < nchunk; ++c) s += slab_w[((int64_t)pair * nchunk + c) * D * D + idx];
     gW[idx] = s;
   }
@@ -518,7 +495,7 @@ extern "C" int cqlrec_encoder_bwd(const float* dH, const uint16_t* z_b, const ui
   do {                                                                                                               \
     hipLaunchKernelGGL(enc_bwd_dx_kernel<DD>, dim3(cql_ceil_div(rows, 32)), dim3(256), 0, s, dH, z_b, W1_b, W2_b,   \
                        rows, dA1, dh0);                                                                              \
-    hipLaunchKernelGGL(enc_bwd_dw_kernel<DD>, dim3((DD / 64) * (DD / 64), nchunk, 2), dim3(256), 0, s, dH, dA1, z_b, \
+    hipLaunchKernelGGL(enc_bwd_dw_kernel<DD>, dim3((DD / 32) * (DD / 32) / 4, nchunk, 2), dim3(256), 0, s, dH, dA1, z_b, \
                        h0_b, rows, slab_w, slab_b, nchunk);                                                          \
     hipLaunchKernelGGL(enc_bwd_reduce_kernel<DD>, dim3(cql_ceil_div(DD * DD, 256), 2), dim3(256), 0, s, slab_w,      \
                        slab_b, nchunk, g_W1, g_b1, g_W2, g_b2);                                                      \
