@@ -214,6 +214,30 @@ class CQLCore:
             dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=self.pg)
         return losses[:n_steps]
 
+    def set_lr(self, lr: float) -> None:
+        self.hyper.lr = float(lr)
+        if self._ctx is not None:
+            self._ctx.lr = float(lr)
+
+    def eval_loss(self, offsets, items, rewards, n_batches: int, seed: int = 12345) -> float:
+        """Mean CQL loss over n_batches sampled batches of ANOTHER log (validation), parameters untouched: the forward
+        phase only (role of TorchRecommender._run_validation, replay/models/base_torch_rec.py:41-55)."""
+        def dev(x, dt):
+            t = torch.as_tensor(np.ascontiguousarray(x) if not torch.is_tensor(x) else x)
+            return t.to(device=self.device, dtype=dt).contiguous()
+        o, it, rw = dev(offsets, torch.int64), dev(items, torch.int32), dev(rewards, torch.float32)
+        if o.numel() < 2 or int(o[-1]) != it.numel() or it.numel() == 0:
+            raise ValueError("inconsistent or empty validation CSR")
+        base = self._train_ctx()
+        c = N.TrainCtx()
+        C.memmove(C.byref(c), C.byref(base), C.sizeof(N.TrainCtx))
+        c.offsets, c.items, c.rewards, c.n_users = _ptr(o), _ptr(it), _ptr(rw), o.numel() - 1
+        c.seed, c.world, c.rank = int(seed), 1, 0
+        losses = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.device)
+        for i in range(n_batches):
+            N.check(self.lib.cqlrec_train_step_forward(C.byref(c), i, _ptr(losses[i:i + 1]), _stream()), "eval forward")
+        return float(losses[:n_batches].mean().item()) if n_batches else float("nan")
+
     def views(self) -> Dict[str, torch.Tensor]:
         """Intermediates of the last forward_backward (tests / debugging).  Copies, synchronises."""
         c = self._train_ctx()

@@ -39,7 +39,9 @@ class CQL(PandasRecommender):
     # pylint: disable=too-many-arguments
     def __init__(self, embedding_dim: int = 128, window: int = 50, batch_size: int = 4096, epochs: int = 1,
                  n_steps: Optional[int] = None, learning_rate: float = 1e-3, gamma: float = 0.99, alpha: float = 1.0,
-                 tau: float = 0.005, seed: int = 0, predict_cold_users: bool = False, device: Optional[str] = None):
+                 tau: float = 0.005, seed: int = 0, predict_cold_users: bool = False, device: Optional[str] = None,
+                 valid_split_size: float = 0.0, patience: int = 3, factor: float = 0.5,
+                 checkpoint_dir: Optional[str] = None):
         if embedding_dim not in (64, 128, 256):
             raise ValueError("embedding_dim must be 64, 128 or 256")
         if window <= 0 or batch_size <= 0 or epochs < 0:
@@ -49,6 +51,14 @@ class CQL(PandasRecommender):
         self.learning_rate, self.gamma, self.alpha, self.tau, self.seed = learning_rate, gamma, alpha, tau, seed
         self.predict_cold_users = predict_cold_users
         self.device = device
+        if not 0.0 <= valid_split_size < 1.0:
+            raise ValueError("valid_split_size must be in [0, 1)")
+        # per-epoch validation, ReduceLROnPlateau and best-epoch checkpoint as TorchRecommender.train does
+        # (replay/models/base_torch_rec.py:57-98; defaults of NeuroMF: replay/models/neuromf.py:222-227, :356-358)
+        self.valid_split_size, self.patience, self.factor = valid_split_size, patience, factor
+        self.checkpoint_dir = checkpoint_dir
+        self.valid_losses: Optional[np.ndarray] = None
+        self.best_epoch: Optional[int] = None
         self.core: Optional[CQLCore] = None
         self.train_losses: Optional[np.ndarray] = None
         self._rank, self._world, self._pg = 0, 1, None
@@ -58,7 +68,8 @@ class CQL(PandasRecommender):
         return {"embedding_dim": self.embedding_dim, "window": self.window, "batch_size": self.batch_size,
                 "epochs": self.epochs, "n_steps": self.n_steps, "learning_rate": self.learning_rate,
                 "gamma": self.gamma, "alpha": self.alpha, "tau": self.tau, "seed": self.seed,
-                "predict_cold_users": self.predict_cold_users}
+                "predict_cold_users": self.predict_cold_users, "valid_split_size": self.valid_split_size,
+                "patience": self.patience, "factor": self.factor}
 
     def set_distributed(self, rank: int, world: int, process_group=None) -> None:
         """Data-parallel training: every rank fits on its own user shard of the log; gradients are summed with RCCL."""
@@ -79,14 +90,53 @@ class CQL(PandasRecommender):
         """Array entry point (what bench.py and a Spark/Arrow adapter call): CSR by user, see data.build_csr."""
         self.core = CQLCore(n_items, self._hyper(), device=self.device, rank=self._rank, world=self._world,
                             process_group=self._pg)
+        to_np = lambda x: x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)   # noqa: E731
+        offsets = to_np(offsets)
+        n_users = len(offsets) - 1
+        n_valid = int(n_users * self.valid_split_size)
+        valid = None
+        if n_valid > 0 and self.n_steps is None and self.epochs > 0:
+            # hold out the LAST n_valid users (rows of one user never straddle the split)
+            cut = int(offsets[n_users - n_valid])
+            items, rewards = to_np(items), to_np(rewards)
+            valid = (offsets[n_users - n_valid:] - cut, items[cut:], rewards[cut:])
+            offsets, items, rewards = offsets[: n_users - n_valid + 1], items[:cut], rewards[:cut]
         self.core.set_log(offsets, items, rewards)
-        nnz = int(np.asarray(offsets[-1].cpu() if torch.is_tensor(offsets) else offsets[-1]))
-        steps = self.n_steps if self.n_steps is not None else self.epochs * math.ceil(nnz / self.batch_size)
-        losses = self.core.train(int(steps))
-        self.train_losses = losses.cpu().numpy()          # the only host sync of fit
+        nnz = int(offsets[-1])
+        if self.n_steps is not None:
+            losses = self.core.train(int(self.n_steps))
+            self.train_losses = losses.cpu().numpy()          # the only host sync of fit
+            return
+        steps_per_epoch = math.ceil(nnz / (self.batch_size * self._world))
+        all_losses, valid_losses = [], []
+        best, best_state, bad_epochs, lr = float("inf"), None, 0, self.learning_rate
+        for epoch in range(self.epochs):
+            all_losses.append(self.core.train(steps_per_epoch))
+            if valid is None:
+                continue
+            n_vb = max(1, math.ceil(int(valid[0][-1]) / self.batch_size))
+            v = self.core.eval_loss(*valid, n_batches=n_vb, seed=self.seed + 1)
+            valid_losses.append(v)
+            self.logger.debug("Epoch[%d] validation average loss: %.5f", epoch, v)
+            if v < best * (1.0 - 1e-4):            # ReduceLROnPlateau(mode="min", threshold=1e-4, "rel")
+                bad_epochs = 0
+            else:
+                bad_epochs += 1
+                if bad_epochs > self.patience:
+                    lr, bad_epochs = lr * self.factor, 0
+                    self.core.set_lr(lr)
+            if v < best:                           # best-epoch checkpoint (base_torch_rec.py:89-97)
+                best, self.best_epoch = v, epoch
+                best_state = {k: (t.clone() if torch.is_tensor(t) else t) for k, t in self.core.state_dict().items()}
+                if self.checkpoint_dir is not None:
+                    torch.save(best_state, f"{self.checkpoint_dir}/best_cql_{epoch + 1}_loss={v}.pt")
+        if best_state is not None:                 # reload the best epoch (base_torch_rec.py:98)
+            self.core.load_state_dict(best_state)
+        self.train_losses = torch.cat(all_losses).cpu().numpy() if all_losses else np.zeros(0, np.float32)
+        self.valid_losses = np.asarray(valid_losses, dtype=np.float64) if valid_losses else None
         if len(self.train_losses):
-            self.logger.debug("CQL fit: %d steps, first/last loss %.5f / %.5f", steps, self.train_losses[0],
-                              self.train_losses[-1])
+            self.logger.debug("CQL fit: %d steps, first/last loss %.5f / %.5f", len(self.train_losses),
+                              self.train_losses[0], self.train_losses[-1])
 
     # ------------------------------------------------------------------------------------------- predict
     def _require_fit(self) -> CQLCore:

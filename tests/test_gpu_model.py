@@ -123,3 +123,34 @@ def test_item_features_and_errors(log, model):
         CQL(embedding_dim=100)
     with pytest.raises(RuntimeError, match="not fitted"):
         CQL(device="cuda:0").predict(log, k=1, users=[0])
+
+
+def test_epochs_validation_plateau_and_best_checkpoint(tmp_path, log):
+    """TorchRecommender.train semantics (replay/models/base_torch_rec.py:57-98): per-epoch validation loss on held-out
+    users, LR reduced on a plateau, the best epoch is what the model ends up with; a checkpoint file appears
+    (reference test: tests/models/test_neuromf.py:123-143)."""
+    m = CQL(embedding_dim=D_, window=L, batch_size=64, epochs=4, seed=3, device="cuda:0", valid_split_size=0.25,
+            patience=0, factor=0.5, learning_rate=5e-3, checkpoint_dir=str(tmp_path))
+    m.fit(log)
+    assert m.valid_losses is not None and len(m.valid_losses) == 4 and np.all(np.isfinite(m.valid_losses))
+    assert m.best_epoch == int(np.argmin(m.valid_losses))
+    files = list(tmp_path.glob("best_cql_*_loss=*.pt"))
+    assert files, "no best-epoch checkpoint written"
+    # the model holds the parameters of the best epoch: its validation loss is reproduced by eval_loss
+    off, items, rew = O.build_csr(log.user_idx, log.item_idx, log.timestamp.values, log.relevance, m._user_dim_size)
+    n_users = len(off) - 1
+    n_valid = int(n_users * 0.25)
+    cut = int(off[n_users - n_valid])
+    v = m.core.eval_loss(off[n_users - n_valid:] - cut, items[cut:], rew[cut:],
+                         n_batches=max(1, -(-int(off[-1] - cut) // 64)), seed=3 + 1)
+    assert abs(v - m.valid_losses.min()) < 1e-5 * abs(v)
+    # validation loss equals the oracle's loss on the same held-out batches
+    lay = O.Layout.make(m.core.n_items, D_)
+    theta, target = m.core.theta.cpu().numpy(), m.core.target.cpu().numpy()
+    vo, vi, vr = off[n_users - n_valid:] - cut, items[cut:], rew[cut:]
+    ref = []
+    for b in range(max(1, -(-int(vo[-1]) // 64))):
+        pos = O.sample_positions(4, b, 0, 64, int(vo[-1]))
+        us, tp = O.positions_to_transitions(pos, vo)
+        ref.append(O.loss_and_grads(lay, theta, target, vo, vi, vr, us, tp, L, 0.99, 1.0).loss)
+    assert abs(v - np.mean(ref)) < 1e-3 * abs(v)
