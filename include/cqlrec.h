@@ -240,6 +240,35 @@ typedef struct cqlrec_train_views {
 int cqlrec_train_views_get(const cqlrec_train_ctx* ctx /* [host] */, cqlrec_train_views* out /* [host] */);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * f2  log -> CSR by user on the device: rows sorted by (user_idx, timestamp asc, item_idx asc), S2.  Takes the place of
+ * `log.toPandas()` + DataLoader construction (replay/models/neuromf.py:332-339).  Inputs are the LOG_SCHEMA columns
+ * (replay/constants.py:16-23) as device arrays; timestamp in any monotone int64 unit.  Bit-exact vs a host lexsort.
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t cqlrec_build_csr_ws_bytes(int64_t n_rows);
+int cqlrec_build_csr(const int32_t* user_idx, const int32_t* item_idx, const int64_t* timestamp,
+                     const double* relevance, int64_t n_rows, int64_t n_users, void* ws, int64_t ws_bytes,
+                     int64_t* offsets /* [n_users+1] */, int32_t* items, float* rewards, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * f4  Quality metrics of a recommendation block on the device, so that optimize()-style loops
+ * (replay/optuna_objective.py:80-111) need not ship U*k rows back through Spark.  Per-user formulas:
+ * replay/metrics/{ndcg.py:50-59, hitrate.py:22-27, precision.py, recall.py, map.py, mrr.py}; user set and
+ * "no recommendations -> empty prediction" as get_enriched_recommendations (replay/metrics/base_metric.py:102-140).
+ *   rec_idx  [n_users x kmax] item ids, best first, unique per row, -1 padded
+ *   rec_rows [n_users] row of the ground-truth CSR for each rec row (NULL: identity)
+ *   gt_off / gt_items  ground-truth CSR, items ascending and unique per row
+ *   ks       [host] n_ks ascending cut-offs (<= kmax, n_ks <= 8)
+ * Output: sums[CQLREC_EVAL_METRICS][n_ks] = per-metric sums over the n_users rows (divide by the number of
+ * ground-truth users); per_user[n_users][CQLREC_EVAL_METRICS][n_ks] optional.  Order: NDCG, HitRate, Precision,
+ * Recall, MAP, MRR.  Double precision, deterministic reduction.
+ * --------------------------------------------------------------------------------------------------------- */
+#define CQLREC_EVAL_METRICS 6
+int64_t cqlrec_eval_topk_ws_bytes(int64_t n_users, int32_t n_ks);
+int cqlrec_eval_topk(const int32_t* rec_idx, int64_t n_users, int32_t kmax, const int32_t* rec_rows,
+                     const int64_t* gt_off, const int32_t* gt_items, const int32_t* ks /* [host] */, int32_t n_ks,
+                     void* ws, int64_t ws_bytes, double* per_user, double* sums, cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, every launcher brackets its kernel with a pair of HIP events on
  * the stream it launches on; cqlrec_prof_read synchronises those events and returns, per phase, the summed
  * kernel time in ms and the number of launches, then resets the pool.  Not capturable in a hipGraph; off by

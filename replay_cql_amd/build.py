@@ -14,7 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcqlrec.so"
-SOURCES = ["misc.hip", "qhead.hip", "topk.hip", "gbwd.hip", "train.hip"]
+SOURCES = ["misc.hip", "qhead.hip", "topk.hip", "gbwd.hip", "prep.hip", "train.hip"]
 # misc.hip holds the Adam kernel whose expression order is normative: no fma contraction anywhere in that file
 EXTRA = {
     "misc.hip": ["-ffp-contract=off"],

@@ -81,9 +81,10 @@ class CQL(PandasRecommender):
                         alpha=self.alpha, lr=self.learning_rate, tau=self.tau, seed=self.seed)
 
     def _fit(self, log: pd.DataFrame, user_features=None, item_features=None) -> None:
-        offsets, items, rewards = D.build_csr(log["user_idx"].to_numpy(), log["item_idx"].to_numpy(),
-                                              log["timestamp"].to_numpy(), log["relevance"].to_numpy(),
-                                              self._user_dim_size)
+        dev = self.device or "cuda"
+        offsets, items, rewards = D.build_csr_device(log["user_idx"].to_numpy(), log["item_idx"].to_numpy(),
+                                                     log["timestamp"].to_numpy(), log["relevance"].to_numpy(),
+                                                     self._user_dim_size, device=dev)      # sort + CSR on the GPU (f2)
         self.fit_arrays(offsets, items, rewards, self._item_dim_size)
 
     def fit_arrays(self, offsets, items, rewards, n_items: int) -> None:
@@ -204,6 +205,42 @@ class CQL(PandasRecommender):
         if not self.predict_cold_users:
             out = out[(offsets[pu + 1] - offsets[pu]) > 0]
         return out
+
+    def evaluate(self, log: pd.DataFrame, ground_truth: pd.DataFrame, ks=(10,), filter_seen_items: bool = True):
+        """Quality of top-max(ks) recommendations for the users of `ground_truth`, computed on the GPU (f4): what
+        optuna_objective.eval_quality (replay/optuna_objective.py:80-111) does with predict + a Spark metric, without
+        the U x k block leaving the device.  Returns {metric: {k: value}} with the reference's metric definitions."""
+        from .metrics import evaluate_topk
+        core = self._require_fit()
+        kmax = int(max(ks))
+        gt = ground_truth[["user_idx", "item_idx"]].drop_duplicates()
+        gt_users = np.sort(gt["user_idx"].unique().astype(np.int64))
+        known = np.isin(gt_users, self.fit_users["user_idx"].to_numpy())        # cold users count with empty predictions
+        offsets, log_items, d_off, d_items = self._states_for(log, gt_users[known] if known.any() else gt_users[:0])
+        has_hist = np.zeros(len(gt_users), dtype=bool)
+        has_hist[known] = (offsets[gt_users[known] + 1] - offsets[gt_users[known]]) > 0
+        rec = torch.full((len(gt_users), kmax), -1, dtype=torch.int32, device=core.device)
+        if has_hist.any():
+            users = torch.as_tensor(gt_users[has_hist].astype(np.int32)).to(core.device)
+            hb = core.encode(d_off, d_items, users)
+            seen = None
+            if filter_seen_items and len(log):
+                seen = (d_off, torch.as_tensor(np.concatenate([D.sorted_seen(offsets, log_items), [0]]).astype(np.int32))
+                        .to(core.device))
+            cand = np.sort(self.fit_items["item_idx"].to_numpy().astype(np.int64))
+            full = len(cand) == core.n_items
+            idx, _, _ = core.score_topk(hb, kmax, cand_items=None if full else torch.as_tensor(cand), seen=seen,
+                                        seen_rows=users if seen is not None else None)
+            rec[torch.as_tensor(np.nonzero(has_hist)[0]).to(core.device)] = idx
+        # ground-truth CSR over the evaluated users (items ascending, unique)
+        row_of = {u: r for r, u in enumerate(gt_users)}
+        rows = gt["user_idx"].map(row_of).to_numpy()
+        order = np.lexsort((gt["item_idx"].to_numpy(), rows))
+        g_items = gt["item_idx"].to_numpy()[order].astype(np.int32)
+        g_off = np.zeros(len(gt_users) + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=len(gt_users)), out=g_off[1:])
+        return evaluate_topk(rec, torch.as_tensor(g_off).to(core.device),
+                             torch.as_tensor(np.concatenate([g_items, [0]]).astype(np.int32)).to(core.device), ks)
 
     def _get_features(self, ids: pd.DataFrame, features):
         """Item embeddings (rows of E_out) in the shape ALS uses (replay/models/als.py:137-148)."""

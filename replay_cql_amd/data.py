@@ -93,3 +93,37 @@ def synth_log_device(n_users: int, n_items: int, seed: int = 12345, device="cuda
     items = ((r * mult + 12345) % n_items).to(torch.int32)
     rewards = ((_lsr(_mix64(hp), 3) % 5 + 1).to(torch.float32)) * 0.2
     return offsets, items.contiguous(), rewards.contiguous()
+
+
+def build_csr_device(user_idx, item_idx, timestamp, relevance, n_users: int, device="cuda"):
+    """build_csr on the GPU (cqlrec_build_csr: three stable rocPRIM radix sorts + boundary scan); returns device
+    tensors (offsets int64[U+1], items int32[nnz], rewards float32[nnz]).  Bit-identical to build_csr()."""
+    from . import _native as N
+    lib = N.load()
+    dev = torch.device(device)
+
+    def col(x, dt):
+        if torch.is_tensor(x):
+            return x.to(device=dev, dtype=dt).contiguous()
+        a = np.asarray(x)
+        if a.dtype.kind == "M":
+            a = a.astype("datetime64[ns]").astype(np.int64)
+        return torch.as_tensor(np.ascontiguousarray(a)).to(device=dev, dtype=dt).contiguous()
+    u, i = col(user_idx, torch.int32), col(item_idx, torch.int32)
+    t, r = col(timestamp, torch.int64), col(relevance, torch.float64)
+    n = u.numel()
+    if not (n == i.numel() == t.numel() == r.numel()):
+        raise ValueError("log columns differ in length")
+    offsets = torch.zeros(n_users + 1, dtype=torch.int64, device=dev)
+    items = torch.empty(n, dtype=torch.int32, device=dev)
+    rewards = torch.empty(n, dtype=torch.float32, device=dev)
+    if n == 0:
+        return offsets, items, rewards
+    if int(u.min()) < 0 or int(i.min()) < 0 or int(u.max()) >= n_users:
+        raise ValueError("user_idx / item_idx must be non-negative dense indices below n_users")
+    ws_bytes = int(lib.cqlrec_build_csr_ws_bytes(n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    N.check(lib.cqlrec_build_csr(u.data_ptr(), i.data_ptr(), t.data_ptr(), r.data_ptr(), n, n_users, ws.data_ptr(),
+                                 ws_bytes, offsets.data_ptr(), items.data_ptr(), rewards.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream), "build_csr")
+    return offsets, items, rewards

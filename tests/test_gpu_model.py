@@ -154,3 +154,22 @@ def test_epochs_validation_plateau_and_best_checkpoint(tmp_path, log):
         us, tp = O.positions_to_transitions(pos, vo)
         ref.append(O.loss_and_grads(lay, theta, target, vo, vi, vr, us, tp, L, 0.99, 1.0).loss)
     assert abs(v - np.mean(ref)) < 1e-3 * abs(v)
+
+
+def test_on_device_evaluation_matches_reference_metric_definitions(log, model):
+    """model.evaluate == the reference's metrics (oracle/metrics_oracle.py, pinned by tests/test_metrics.py values)
+    applied to model.predict output."""
+    from oracle import metrics_oracle as M
+    rng = np.random.default_rng(2)
+    test = log.sample(frac=0.15, random_state=1)[["user_idx", "item_idx"]]
+    extra = pd.DataFrame({"user_idx": [10_000, 10_000], "item_idx": [1, 2]})       # a cold user in the ground truth
+    test = pd.concat([test, extra], ignore_index=True)
+    train = log.drop(test.index, errors="ignore")
+    ks = [1, 5, 10]
+    got = model.evaluate(train, test, ks=ks)
+    recs = model.predict(train, k=10, users=test.user_idx.unique())
+    ref = M.evaluate(recs.user_idx, recs.item_idx, recs.relevance, test.user_idx, test.item_idx, ks)
+    name = {"ndcg": "NDCG", "hitrate": "HitRate", "precision": "Precision", "recall": "Recall", "map": "MAP", "mrr": "MRR"}
+    for m, d in ref.items():
+        for k, v in d.items():
+            assert got[name[m]][k] == pytest.approx(v, rel=1e-9, abs=1e-12), (m, k)

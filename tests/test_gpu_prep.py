@@ -1,0 +1,92 @@
+"""GPU parity of the (f2) CSR builder and the (f4) evaluation kernel -- the latter against the reference's own known
+answers (tests/test_metrics.py fixtures, re-typed in test_metrics_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cql_oracle as O
+from oracle import metrics_oracle as M
+from replay_cql_amd import data as D
+from replay_cql_amd.metrics import METRICS, evaluate_topk
+
+from test_metrics_oracle import EXPECTED, RECS, TRUE, TRUE_USERS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n,U,NI", [(11, 4, 4), (5000, 300, 97), (1_000_000, 20_000, 5_000)])
+def test_build_csr_device_bit_exact(n, U, NI):
+    rng = np.random.default_rng(n)
+    u = rng.integers(0, U, n).astype(np.int32)
+    u[u == 3] = 2                                   # an empty user in the middle
+    i = rng.integers(0, NI, n).astype(np.int32)
+    t = rng.integers(-50, 50, n).astype(np.int64) * 10**9      # many timestamp ties, negative values
+    r = (rng.integers(1, 6, n) / 5.0)
+    off, items, rew = D.build_csr_device(u, i, t, r, U, device=DEV)
+    ro, ri, rr = O.build_csr(u, i, t, r, U)
+    assert np.array_equal(off.cpu().numpy(), ro)
+    assert np.array_equal(items.cpu().numpy(), ri)
+    assert np.array_equal(rew.cpu().numpy(), rr)
+    ho, hi, hr = D.build_csr(u, i, t, r, U)         # and the host builder of the product agrees too
+    assert np.array_equal(ho, ro) and np.array_equal(hi, ri) and np.array_equal(hr, rr)
+
+
+def test_build_csr_device_datetime_and_validation():
+    ts = np.array(["2020-01-02", "2020-01-01", "2020-01-01"], dtype="datetime64[ns]")
+    off, items, rew = D.build_csr_device([0, 0, 0], [5, 9, 7], ts, [1.0, 2.0, 3.0], 2, device=DEV)
+    assert off.tolist() == [0, 3, 3] and items.tolist() == [7, 9, 5] and rew.tolist() == [3.0, 2.0, 1.0]
+    with pytest.raises(ValueError):
+        D.build_csr_device([0, 5], [1, 2], [0, 1], [1.0, 1.0], 2, device=DEV)
+
+
+def _block_from_frames(recs, true, users, kmax):
+    rec = -np.ones((len(users), kmax), dtype=np.int32)
+    for row, u in enumerate(users):
+        mine = sorted([(-rel, it) for uu, it, rel in recs if uu == u])[:kmax]
+        for j, (_, it) in enumerate(mine):
+            rec[row, j] = it
+    cnt = [len([1 for uu, _ in true if uu == u]) for u in users]
+    off = np.zeros(len(users) + 1, dtype=np.int64)
+    np.cumsum(cnt, out=off[1:])
+    gt = np.array([it for u in users for it in sorted(i for uu, i in true if uu == u)], dtype=np.int32)
+    return rec, off, (gt if len(gt) else np.zeros(1, np.int32))
+
+
+@pytest.mark.parametrize("gt_users", [False, True])
+def test_eval_kernel_reproduces_reference_known_answers(gt_users):
+    users = TRUE_USERS if gt_users else sorted({u for u, _ in TRUE})
+    rec, off, gt = _block_from_frames(RECS, TRUE, users, 3)
+    got = evaluate_topk(torch.as_tensor(rec).to(DEV), torch.as_tensor(off).to(DEV), torch.as_tensor(gt).to(DEV), [1, 3])
+    name = {"ndcg": "NDCG", "hitrate": "HitRate", "precision": "Precision", "map": "MAP", "recall": "Recall"}
+    for metric, exp in EXPECTED[gt_users].items():
+        for k, v in exp.items():
+            assert got[name[metric]][k] == pytest.approx(v, rel=1e-12, abs=1e-15), (metric, k)
+
+
+def test_eval_kernel_matches_oracle_on_random_blocks():
+    rng = np.random.default_rng(1)
+    n, kmax, NI = 3000, 20, 500
+    rec = np.stack([rng.permutation(NI)[:kmax] for _ in range(n)]).astype(np.int32)
+    rec[5, 7:] = -1
+    rec[9, :] = -1
+    cnt = rng.integers(0, 30, n)
+    cnt[11] = 0
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(cnt, out=off[1:])
+    gt = np.concatenate([np.sort(rng.choice(NI, c, replace=False)) for c in cnt]).astype(np.int32)
+    ks = [1, 5, 10, 20]
+    out, per_user = evaluate_topk(torch.as_tensor(rec).to(DEV), torch.as_tensor(off).to(DEV), torch.as_tensor(gt).to(DEV),
+                                  ks, return_per_user=True)
+    ref = M.evaluate_block(rec, off, gt, ks)
+    np.testing.assert_allclose(per_user.cpu().numpy(), ref, rtol=1e-13, atol=1e-15)
+    for mi, m in enumerate(METRICS):
+        for ki, k in enumerate(ks):
+            assert out[m][k] == pytest.approx(ref[:, mi, ki].mean(), rel=1e-12)
+    # row indirection: evaluate a permuted subset of users against the same CSR
+    rows = rng.permutation(n)[:700].astype(np.int32)
+    out2 = evaluate_topk(torch.as_tensor(rec[rows]).to(DEV), torch.as_tensor(off).to(DEV), torch.as_tensor(gt).to(DEV), ks,
+                         rec_rows=torch.as_tensor(rows).to(DEV))
+    for mi, m in enumerate(METRICS):
+        for ki, k in enumerate(ks):
+            assert out2[m][k] == pytest.approx(ref[rows][:, mi, ki].mean(), rel=1e-12)
