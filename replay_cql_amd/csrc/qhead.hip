@@ -404,11 +404,10 @@ int qs_spw_fwd(int d) {
   return (v == 4 && d <= 128) ? 4 : 2;
 }
 
-QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows) {
+QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int target) {
   QSplit s;
   s.rblks = (n_res + 128 * spw - 1) / (128 * spw);
   const int64_t units = (n_str + unit_rows - 1) / unit_rows;
-  static const int target = qs_env_int("CQL_QS_BLOCKS", QS_TARGET_BLOCKS);
   int64_t want = (target + s.rblks - 1) / s.rblks;
   int64_t max_split = units / 2;  // at least two units of streamed rows per slice
   if (max_split < 1) max_split = 1;
@@ -620,7 +619,7 @@ static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" int64_t cqlrec_qhead_ws_bytes(int64_t rows, int64_t n_items, int32_t d) {
   (void)d;
-  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI);
+  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI, QS_TARGET_BLOCKS);
   return 3 * align256((int64_t)sp.nsplit * rows * 4) + 256;
 }
 
@@ -632,7 +631,7 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
   CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
   CQL_REQUIRE(mode == CQLREC_QHEAD_LSE || mode == CQLREC_QHEAD_ARGMAX, "qhead_fwd: bad mode %d", mode);
   CQL_REQUIRE(ws_bytes >= cqlrec_qhead_ws_bytes(rows, n_items, d), "qhead_fwd: workspace too small");
-  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI);
+  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI, QS_TARGET_BLOCKS);
   const int64_t seg = align256((int64_t)sp.nsplit * rows * 4);
   QArgs a = {};
   a.res = H_b;
@@ -669,8 +668,8 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
 }
 
 extern "C" int64_t cqlrec_qhead_bwd_ws_bytes(int64_t batch, int64_t n_items, int32_t d) {
-  const QSplit s1 = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI);
-  const QSplit s2 = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI);
+  const QSplit s1 = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
+  const QSplit s2 = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
   const int64_t a1 = align256((int64_t)s1.nsplit * batch * d * 4);
   const int64_t a2 = align256((int64_t)s2.nsplit * n_items * d * 4) + align256((int64_t)s2.nsplit * n_items * 4);
   return (a1 > a2 ? a1 : a2) + 256;
@@ -686,7 +685,7 @@ extern "C" int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, 
   CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd_states: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
   CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd_states: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const QSplit sp = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI);
+  const QSplit sp = qs_choose_split(n_items, batch, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
   QArgs a = {};
   a.res = H_b;
   a.n_res = batch;
@@ -721,37 +720,50 @@ extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, c
   CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd_items: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
   CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd_items: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const QSplit sp = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI);
-  QArgs a = {};
-  a.res = E_out_b;
-  a.n_res = n_items;
-  a.str = H_b;
-  a.n_str = batch;
-  a.str_scalar = nlse2;
-  a.res_scalar = b_out;
-  a.nsplit = sp.nsplit;
-  a.split_rows = sp.split_rows;
-  a.slab = (float*)ws;
-  a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * n_items * d * 4));
-  a.tg = 1;
-  const bool direct = (sp.nsplit == 1);
-  if (direct) {   // one slice: the kernel scales and writes g_E_out / g_b_out itself
-    a.out = g_E_out;
-    a.out_cs = g_b_out;
-    a.scale = scale;
-  }
-  qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
-  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
   dim3 block(256);
-  if (!direct) {
-    const int64_t n4 = n_items * (d / 4);
-    dim3 grid(cql_ceil_div(n4, 256));
-#define RED_DE(DD)                                                                                              \
-  hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, a.slab_cs, a.nsplit, n_items, scale, \
-                     (const float*)nullptr, (const int32_t*)nullptr, (const uint16_t*)nullptr, g_E_out, g_b_out)
-    if (d == 64) RED_DE(64); else if (d == 128) RED_DE(128); else RED_DE(256);
+  // Large catalogues: one block per 128 items streams every state and writes its rows directly (no cross-block
+  // sum).  Small catalogues: the state axis is split too, slabs are summed by the small reduce kernel.  (A third
+  // variant -- a whole number of resident "rounds" first, the remainder with split states -- measured no faster:
+  // the step driver instead runs this kernel concurrently with the state-side kernel, which fills the idle CUs of
+  // the last round.)
+  auto launch_range = [&](int64_t row0, int64_t count, bool allow_direct) {
+    const QSplit sp = (allow_direct)
+                          ? qs_choose_split(batch, count, QS_SPW_BWD, QS_TI, 1)
+                          : qs_choose_split(batch, count, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
+    QArgs a = {};
+    a.res = E_out_b + row0 * d;
+    a.n_res = count;
+    a.str = H_b;
+    a.n_str = batch;
+    a.str_scalar = nlse2;
+    a.res_scalar = b_out + row0;
+    a.nsplit = sp.nsplit;
+    a.split_rows = sp.split_rows;
+    a.slab = (float*)ws;
+    a.slab_cs = (float*)((char*)ws + align256((int64_t)sp.nsplit * count * d * 4));
+    a.tg = 1;
+    const bool direct = (sp.nsplit == 1);
+    if (direct) {   // one slice: the kernel scales and writes g_E_out / g_b_out itself
+      a.out = g_E_out + row0 * d;
+      a.out_cs = g_b_out + row0;
+      a.scale = scale;
+    }
+    qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
+    if (!direct) {
+      CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+      const int64_t n4 = count * (d / 4);
+      dim3 grid(cql_ceil_div(n4, 256));
+#define RED_DE(DD)                                                                                            \
+  hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, a.slab_cs, a.nsplit, count, scale, \
+                     (const float*)nullptr, (const int32_t*)nullptr, (const uint16_t*)nullptr,                 \
+                     g_E_out + row0 * d, g_b_out + row0)
+      if (d == 64) RED_DE(64); else if (d == 128) RED_DE(128); else RED_DE(256);
 #undef RED_DE
-  }
+    }
+  };
+  const int64_t rblks_all = (n_items + 127) / 128;
+  launch_range(0, n_items, rblks_all >= QS_TARGET_BLOCKS_BWD);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
   dim3 g2(cql_ceil_div(batch, 4));
 #define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
   if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);

@@ -11,7 +11,8 @@
 #define QS_TI 64            // host-side unit of streamed rows (split boundaries are multiples of it)
 #define QS_SPW_FWD 2        // 32-row owner groups per wave, forward modes (64 states per wave, 256 per block)
 #define QS_SPW_BWD 1        // backward modes (32 owners per wave, 128 per block)
-#define QS_TARGET_BLOCKS 768
+#define QS_TARGET_BLOCKS 768      // forward modes: 3 blocks per CU resident
+#define QS_TARGET_BLOCKS_BWD 512  // backward modes: 2 blocks per CU resident (register budget)
 #define QS_NBUF 3             // LDS stage buffers (prefetch distance NBUF-1 stages)
 
 struct QArgs {
@@ -43,5 +44,5 @@ struct QSplit {
 };
 
 int qs_spw_fwd(int d);
-QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows);
+QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int target_blocks);
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);

@@ -384,7 +384,7 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   hipStream_t s = (hipStream_t)stream;
   // pass 1
   const int unit = (32 * tg > QS_TI) ? 32 * tg : QS_TI;
-  const QSplit sp = qs_choose_split(n_cand, n_users, qs_spw_fwd(d), unit);
+  const QSplit sp = qs_choose_split(n_cand, n_users, qs_spw_fwd(d), unit, QS_TARGET_BLOCKS);
   QArgs a = {};
   a.res = H_b;
   a.n_res = n_users;

@@ -21,7 +21,7 @@ struct StepWs {
   float *rew, *done, *q_a, *lse, *nlse2, *q_targ, *y, *coef, *maxv, *loss;
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
-  void *ws_q, *ws_qb, *ws_enc, *ws_gb;
+  void *ws_q, *ws_qb, *ws_qb2, *ws_enc, *ws_gb;
   int64_t ws_q_bytes, ws_qb_bytes, ws_enc_bytes, ws_gb_bytes;
   int64_t total;
 };
@@ -55,7 +55,8 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L) {
   w.ws_q_bytes = cqlrec_qhead_ws_bytes(B, N, d);
   w.ws_q = c.take<char>(w.ws_q_bytes);
   w.ws_qb_bytes = cqlrec_qhead_bwd_ws_bytes(B, N, d);
-  w.ws_qb = c.take<char>(w.ws_qb_bytes);
+  w.ws_qb = c.take<char>(w.ws_qb_bytes);    // state-side backward (dH slabs)
+  w.ws_qb2 = c.take<char>(w.ws_qb_bytes);   // item-side backward: its own scratch, the two kernels run concurrently
   w.ws_enc_bytes = cqlrec_encoder_bwd_ws_bytes(B, d);
   w.ws_enc = c.take<char>(w.ws_enc_bytes);
   w.ws_gb_bytes = cqlrec_gather_pool_bwd_ws_bytes(B, L, d);
@@ -187,7 +188,7 @@ extern "C" int cqlrec_train_step_backward_items(const cqlrec_train_ctx* c, uint6
   const StepPtrs p = step_ptrs(c);
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
   return cqlrec_qhead_bwd_items(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
-                                w.ws_qb, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out, stream);
+                                w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out, stream);
 }
 
 // phase 3: dH, encoder backward, window-gather backward (joins the side stream)
@@ -216,6 +217,30 @@ extern "C" int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* c, uint64
 extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
                                          cqlrec_stream stream) {
   CQL_TRY(cqlrec_train_step_forward(c, step, loss_out, stream));
+  // The item-side and the state-side halves of the Q-head backward are independent.  Each alone leaves part of the
+  // chip idle in its last "round" of resident blocks (782 resp. 512 blocks on 512 slots at cfg3); issued on two
+  // streams, the hardware scheduler packs them.  Fork after the loss, join before returning.
+  SideStream& ss = side_stream();
+  hipStream_t s = (hipStream_t)stream;
+  static hipEvent_t ev_loss = nullptr, ev_items = nullptr;
+  if (ss.ok && !ev_loss) {
+    if (hipEventCreateWithFlags(&ev_loss, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_items, hipEventDisableTiming) != hipSuccess)
+      ss.ok = false;
+  }
+  if (ss.ok && hipEventRecord(ev_loss, s) == hipSuccess && hipStreamWaitEvent(ss.s, ev_loss, 0) == hipSuccess) {
+    CQL_TRY(cqlrec_train_step_backward_items(c, step, (cqlrec_stream)ss.s));
+    if (hipEventRecord(ev_items, ss.s) != hipSuccess) {
+      cql_set_error("train_step_fwd_bwd: hipEventRecord failed");
+      return CQLREC_ERR_HIP;
+    }
+    CQL_TRY(cqlrec_train_step_backward_rest(c, step, stream));
+    if (hipStreamWaitEvent(s, ev_items, 0) != hipSuccess) {
+      cql_set_error("train_step_fwd_bwd: hipStreamWaitEvent failed");
+      return CQLREC_ERR_HIP;
+    }
+    return CQLREC_OK;
+  }
   CQL_TRY(cqlrec_train_step_backward_items(c, step, stream));
   return cqlrec_train_step_backward_rest(c, step, stream);
 }
