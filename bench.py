@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--serial", action="store_true",
+                    help="no intra-step concurrency for the whole run (per-kernel durations then match rocprofv3)")
     return ap.parse_args()
 
 
@@ -125,6 +127,8 @@ def main():
         for i in range(n):
             core.train_step(loss_buf[base + i: base + i + 1])
 
+    if args.serial:
+        N.check(lib.cqlrec_set_concurrency(0), "set_concurrency")
     run(args.warmup, 0)
     barrier()
     if not args.no_prof:
@@ -133,8 +137,26 @@ def main():
     run(args.steps, args.warmup)
     barrier()
     dt = time.perf_counter() - t0
-    phases = N.prof_read() if not args.no_prof else {}
+    phases_timed = N.prof_read() if not args.no_prof else {}
     N.check(lib.cqlrec_prof_enable(0), "prof_enable")
+    # Per-kernel durations for the roofline: inside the timed region independent kernels overlap on side streams, so a
+    # kernel's event-bracketed duration there includes what it shared the chip with.  A short serialised pass in the
+    # same process (same data, same shapes, not part of `value`) gives each kernel's own launch duration.
+    phases = phases_timed
+    n_prof_steps = args.steps
+    if not args.no_prof and not args.serial:
+        n_prof_steps = 10
+        N.check(lib.cqlrec_set_concurrency(0), "set_concurrency")
+        spare = torch.zeros(n_prof_steps + 1, device=dev)
+        core.train_step(spare[:1])
+        barrier()
+        N.check(lib.cqlrec_prof_enable(1), "prof_enable")
+        for i in range(n_prof_steps):
+            core.train_step(spare[i + 1: i + 2])
+        barrier()
+        phases = N.prof_read()
+        N.check(lib.cqlrec_prof_enable(0), "prof_enable")
+        N.check(lib.cqlrec_set_concurrency(1), "set_concurrency")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -200,8 +222,12 @@ def main():
         "loss_first_last": [losses[0], losses[-1]] if losses else None,
     }
     if phases:
-        per = {p: {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps} for p, (ms, n) in phases.items() if n}
-        out["kernel_ms_per_step"] = {p: round(v["ms_per_step"], 4) for p, v in per.items()}
+        out["kernel_ms_per_step"] = {p: round(ms / n_prof_steps, 4) for p, (ms, n) in phases.items() if n}
+        out["kernel_ms_note"] = ("serialised pass of %d steps after the timed region (intra-step concurrency off); "
+                                 "in the timed region independent kernels overlap" % n_prof_steps) if not args.serial \
+            else "timed region (run with --serial)"
+        if phases_timed is not phases:
+            out["kernel_ms_per_step_overlapped"] = {p: round(ms / args.steps, 4) for p, (ms, n) in phases_timed.items() if n}
         qk = {p: phases[p][0] / max(phases[p][1], 1) for p in ("qhead_lse", "qhead_argmax", "qhead_bwd_dh", "qhead_bwd_de")}
         dom = max(qk, key=qk.get)
         flops = 2.0 * B * NI * d          # algorithmic flops of ONE Q-head GEMM (8*B*N*d per step = 4 GEMMs)

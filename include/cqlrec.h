@@ -231,6 +231,11 @@ int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* ctx /* [host] */, ui
 int cqlrec_train_step_update_range(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, int64_t lo, int64_t hi,
                                    cqlrec_stream stream);
 
+/* 1 (default; env CQL_CONCURRENCY=0 to disable): independent parts of a step (the sort for the gather backward, the
+ * two forward branches, the item-side vs state-side Q-head backward) run on internal side streams, forked and joined
+ * with events on `stream`.  0: strict program order on `stream` -- use it when timing individual kernels. */
+int cqlrec_set_concurrency(int32_t on);
+
 /* Debug/inspection of the step's intermediates inside ctx->ws (device pointers; valid after fwd_bwd). */
 typedef struct cqlrec_train_views {
   int32_t *users, *tpos, *act, *a_star;

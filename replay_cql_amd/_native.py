@@ -89,6 +89,7 @@ SIGNATURES = {
     "cqlrec_train_step_backward_items": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_backward_rest": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),
+    "cqlrec_set_concurrency": (i32, [i32]),
     "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), C.POINTER(TrainViews)]),
     "cqlrec_build_csr_ws_bytes": (i64, [i64]),
     "cqlrec_build_csr": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),

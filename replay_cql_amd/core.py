@@ -69,6 +69,7 @@ class CQLCore:
         self._csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._ws: Optional[torch.Tensor] = None
         self._ctx: Optional[N.TrainCtx] = None
+        self._side: Optional[torch.cuda.Stream] = None
         self.init_params(init_seed)
 
     # ------------------------------------------------------------------ parameters
@@ -182,13 +183,23 @@ class CQLCore:
             return
         c, s, lay = self._train_ctx(), _stream(), self.layout
         lo_a, hi_a, total = int(lay.off_E_out), int(lay.off_W1), int(lay.total)
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
         N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(loss_out), s), "train_step_forward")
-        N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, s), "train_step_backward_items")
-        work_a = self._allreduce_async(self.grads[lo_a:hi_a])
+        # item-side backward (+ its all-reduce) on a side stream, concurrently with the state-side backward
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
+                    "train_step_backward_items")
+            work_a = self._allreduce_async(self.grads[lo_a:hi_a])
         N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
         work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
         if work_a is not None:
             work_a.wait()          # stream-side wait (RCCL): no host block
+        else:
+            main.wait_stream(side)
         N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, lo_a, hi_a, s), "update_range")
         for w in work_b:
             if w is not None:

@@ -1,7 +1,10 @@
 // Training-step driver (a8): enqueues the whole CQL step on one stream, no host sync, no allocation.
 // Split in two halves so that a data-parallel caller can all-reduce ctx->grads (RCCL over xGMI) in between.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
+
+static int g_concurrency = -1;   // -1: read CQL_CONCURRENCY on first use (default on)
 
 namespace {
 struct Carve {
@@ -21,7 +24,7 @@ struct StepWs {
   float *rew, *done, *q_a, *lse, *nlse2, *q_targ, *y, *coef, *maxv, *loss;
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
-  void *ws_q, *ws_qb, *ws_qb2, *ws_enc, *ws_gb;
+  void *ws_q, *ws_q2, *ws_qb, *ws_qb2, *ws_enc, *ws_gb;
   int64_t ws_q_bytes, ws_qb_bytes, ws_enc_bytes, ws_gb_bytes;
   int64_t total;
 };
@@ -53,7 +56,8 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L) {
   w.zb_t = c.take<uint16_t>((int64_t)B * d);
   w.hb_t = c.take<uint16_t>((int64_t)B * d);
   w.ws_q_bytes = cqlrec_qhead_ws_bytes(B, N, d);
-  w.ws_q = c.take<char>(w.ws_q_bytes);
+  w.ws_q = c.take<char>(w.ws_q_bytes);     // LSE partials (branch A)
+  w.ws_q2 = c.take<char>(w.ws_q_bytes);    // ARGMAX partials (branch B runs concurrently)
   w.ws_qb_bytes = cqlrec_qhead_bwd_ws_bytes(B, N, d);
   w.ws_qb = c.take<char>(w.ws_qb_bytes);    // state-side backward (dH slabs)
   w.ws_qb2 = c.take<char>(w.ws_qb_bytes);   // item-side backward: its own scratch, the two kernels run concurrently
@@ -81,6 +85,13 @@ int check_ctx(const cqlrec_train_ctx* c) {
 }
 }  // namespace
 
+// 1 (default): independent parts of the step run on internal side streams (fork/join by events); 0: everything on the
+// caller's stream in program order (used for per-kernel timing, where overlapped launches would blur the durations)
+extern "C" int cqlrec_set_concurrency(int32_t on) {
+  g_concurrency = on ? 1 : 0;
+  return CQLREC_OK;
+}
+
 extern "C" int64_t cqlrec_train_ws_bytes(int32_t batch, int64_t n_items, int32_t d, int32_t window) {
   return carve_step(nullptr, batch, n_items, d, window).total + 256;
 }
@@ -95,16 +106,31 @@ namespace {
 // side stream for the part of the gather backward that depends only on the sampled batch (pairs + radix sort): it
 // runs underneath the Q-head kernels.  Fork/join through events, so the structure stays capturable in a hipGraph.
 struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t forked = nullptr, joined = nullptr;
+  hipStream_t s = nullptr;    // sort of the gather backward (forward phase), item-side backward (backward phase)
+  hipStream_t s2 = nullptr;   // branch B of the forward (s' rows: argmax + target network)
+  hipEvent_t forked = nullptr, joined = nullptr, fork2 = nullptr, join2 = nullptr;
   bool ok = false;
+  bool tried = false;
 };
+bool concurrency_on() {
+  if (g_concurrency < 0) {
+    const char* v = getenv("CQL_CONCURRENCY");
+    g_concurrency = (v && *v == '0') ? 0 : 1;
+  }
+  return g_concurrency != 0;
+}
 SideStream& side_stream() {
   static SideStream ss;
-  if (!ss.ok) {
+  static SideStream off;   // never ok: serial mode
+  if (!concurrency_on()) return off;
+  if (!ss.tried) {
+    ss.tried = true;
     ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.forked, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.joined, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ss.joined, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork2, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess;
   }
   return ss;
 }
@@ -156,20 +182,32 @@ extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t ste
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            stream));
   }
-  // state vectors: s, s' under theta; s' under the target net
+  // The forward has two independent branches that meet at the TD target:
+  //   A (this stream):  s  under theta  -> encoder -> logsumexp over the catalogue, Q(s, a)
+  //   B (side stream):  s' under theta  -> encoder -> argmax;  s' under the target net -> encoder -> Q_target(s', a*)
+  // Run concurrently, the small gather / encoder / finalize launches of one branch fill the launch gaps of the other.
+  cqlrec_stream sb = stream;
+  const bool par = ss.ok && hipEventRecord(ss.fork2, s) == hipSuccess && hipStreamWaitEvent(ss.s2, ss.fork2, 0) == hipSuccess;
+  if (par) sb = (cqlrec_stream)ss.s2;
+  // ---- branch A
   CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, w.h0_s, w.h0b, nullptr, stream));
-  CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, stream));
-  CQL_TRY(cqlrec_gather_pool_fwd(p.tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, stream));
-  // encoder
-  CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, 2 * (int64_t)B, d, 1, nullptr, w.zb, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, 2 * (int64_t)B, d, 0, nullptr, w.hb, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, stream));
-  // Q-head: logsumexp over the catalog for s, argmax for s'
+  CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, B, d, 1, nullptr, w.zb, stream));
+  CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, B, d, 0, nullptr, w.hb, stream));
   CQL_TRY(cqlrec_qhead_fwd(w.hb, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_LSE, w.ws_q, w.ws_q_bytes, w.lse, nullptr, w.nlse2, stream));
-  CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q, w.ws_q_bytes, w.maxv, w.a_star, nullptr, stream));
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
-  CQL_TRY(cqlrec_gather_dot(w.hb_t, p.tEout_b, p.tb_out, w.a_star, B, d, w.q_targ, stream));
+  // ---- branch B
+  CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, sb));
+  CQL_TRY(cqlrec_gather_pool_fwd(p.tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, sb));
+  CQL_TRY(cqlrec_linear_bf16(w.h0b + Bd, p.W1_b, p.b1, B, d, 1, nullptr, w.zb + Bd, sb));
+  CQL_TRY(cqlrec_linear_bf16(w.zb + Bd, p.W2_b, p.b2, B, d, 0, nullptr, w.hb + Bd, sb));
+  CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, sb));
+  CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, sb));
+  CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star, nullptr, sb));
+  CQL_TRY(cqlrec_gather_dot(w.hb_t, p.tEout_b, p.tb_out, w.a_star, B, d, w.q_targ, sb));
+  if (par && (hipEventRecord(ss.join2, ss.s2) != hipSuccess || hipStreamWaitEvent(s, ss.join2, 0) != hipSuccess)) {
+    cql_set_error("train_step_forward: joining the forward branches failed");
+    return CQLREC_ERR_HIP;
+  }
   // loss + dQ coefficients
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
   CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, c->gamma, c->alpha, inv_batch, w.coef, w.y,
