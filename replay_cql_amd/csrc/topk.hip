@@ -12,6 +12,7 @@
 //                    when no unprocessed group can beat tau -- usually after k + (a few) groups of 32 items.
 //           finally rank the k survivors and write (item id, score).
 //   Ordering is exactly (score desc, item id asc) -- the tie rule of SURVEY.md F7 / 8.0 S7.
+#include <stdlib.h>
 #include "qhead_internal.h"
 
 #define TK_CB_SMALL 1024    // candidate buffer entries (LDS, 8 KiB): k <= 512
@@ -346,6 +347,214 @@ __global__ __launch_bounds__(64) void topk_select_kernel(const uint16_t* __restr
 }
 
 // =============================================================================================================
+// k <= 16: the common case, with far fewer instructions per user than the radix-select kernel above.
+//   * every lane keeps the best TWO of its unprocessed group keys; the next-best group of the user is a wave-wide
+//     max over the lanes' bests (when a lane has given away both, all lanes refill -- rare);
+//   * groups are visited strictly in (max desc, group asc) order, one at a time, until the bound of the next one
+//     cannot beat tau -- the threshold algorithm in its plain form;
+//   * "the k best of the candidates" is k rounds of wave-wide max over register-held keys, which also leaves them
+//     sorted, so the final ranking is free.
+// Same exactness argument and identical results as topk_select_kernel (tests run both).
+// =============================================================================================================
+#define TKS_MAX_K 16
+#define TKS_CB 512           // candidate capacity in LDS = 8 register slots per lane
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int D, int KPL>
+__global__ __launch_bounds__(64) void topk_select_small_kernel(const uint16_t* __restrict__ H_b, int64_t n_users,
+                                                               const uint16_t* __restrict__ E_b,
+                                                               const float* __restrict__ b, int64_t n_cand,
+                                                               const int32_t* __restrict__ item_ids,
+                                                               const int64_t* __restrict__ seen_off,
+                                                               const int32_t* __restrict__ seen_items,
+                                                               const int32_t* __restrict__ seen_rows,
+                                                               const float* __restrict__ tm_t, int gstride, int ngroups,
+                                                               int tg, int k, int32_t* __restrict__ out_idx,
+                                                               float* __restrict__ out_val, int32_t* __restrict__ out_cnt) {
+  constexpr int KS = D / 16;
+  __shared__ __attribute__((aligned(16))) float scores[32];
+  __shared__ uint64_t cand[TKS_CB];
+  __shared__ uint64_t best[TKS_MAX_K];
+  __shared__ int32_t seen_lds[TK_SEEN_LDS];
+
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int64_t u = blockIdx.x;
+  const int64_t srow = seen_rows ? (int64_t)seen_rows[u] : u;
+  const int64_t so = seen_off ? seen_off[srow] : 0;
+  const int ns = seen_off ? (int)(seen_off[srow + 1] - so) : 0;
+  const unsigned long long lt_mask = (1ull << lane) - 1;
+
+  uint32_t key[KPL];
+#pragma unroll
+  for (int sl = 0; sl < KPL; ++sl) {
+    const int g = sl * 64 + lane;
+    key[sl] = (g < ngroups) ? f32_order_key(tm_t[u * gstride + g]) : 0u;   // real keys are > 0
+  }
+  const bool seen_in_lds = ns <= TK_SEEN_LDS;
+  if (seen_in_lds) {
+    for (int i = lane; i < ns; i += 64) seen_lds[i] = seen_items[so + i];
+  }
+  bf16x8 hf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(H_b + u * D + 16 * s + 8 * h);
+  __syncthreads();
+
+  // ---- per-lane best two unprocessed groups (key, slot); key 0 = none ----------------------------------------------
+  const int nvalid = (ngroups > lane) ? (ngroups - lane + 63) / 64 : 0;   // slots of this lane that hold a group
+  unsigned long long done = 0;
+  uint32_t b1k = 0, b2k = 0;
+  int b1s = 0, b2s = 0;
+  auto refill = [&]() {
+    b1k = 0; b2k = 0; b1s = 0; b2s = 0;
+#pragma unroll
+    for (int sl = 0; sl < KPL; ++sl) {
+      const uint32_t kk = ((done >> sl) & 1ull) ? 0u : key[sl];
+      const bool gt1 = kk > b1k, gt2 = kk > b2k;        // ascending slots + strict '>' keep the earliest on ties
+      b2k = gt1 ? b1k : (gt2 ? kk : b2k);
+      b2s = gt1 ? b1s : (gt2 ? sl : b2s);
+      b1k = gt1 ? kk : b1k;
+      b1s = gt1 ? sl : b1s;
+    }
+  };
+  refill();
+
+  int ncand = 0;
+  uint64_t tau = 0;        // k-th best candidate key (valid once have_k)
+  bool have_k = false;
+
+  // the k best of cand[0..ncand): k rounds of wave max over register-held keys -> best[] (descending), compacted back
+  auto take_top_k = [&]() {
+    uint64_t ck[TKS_CB / 64];
+#pragma unroll
+    for (int q = 0; q < TKS_CB / 64; ++q) ck[q] = (q * 64 + lane < ncand) ? cand[q * 64 + lane] : 0ull;
+    const int kk = k < ncand ? k : ncand;
+    for (int j = 0; j < kk; ++j) {
+      uint64_t m = 0;
+#pragma unroll
+      for (int q = 0; q < TKS_CB / 64; ++q) m = ck[q] > m ? ck[q] : m;
+      const uint64_t w = wave_max_u64(m);
+#pragma unroll
+      for (int q = 0; q < TKS_CB / 64; ++q) ck[q] = (ck[q] == w) ? 0ull : ck[q];   // keys are distinct
+      if (lane == 0) best[j] = w;
+    }
+    __syncthreads();
+    if (lane < kk) cand[lane] = best[lane];
+    ncand = kk;
+    have_k = (kk == k);
+    tau = have_k ? best[k - 1] : 0ull;
+    __syncthreads();
+  };
+
+  auto rescore = [&](int g) {
+    for (int t = 0; t < tg; ++t) {
+      const int64_t item0 = ((int64_t)g * tg + t) * 32;
+      if (item0 >= n_cand) break;
+      if (ncand + 32 > TKS_CB) take_top_k();
+      int64_t arow = item0 + r;
+      if (arow >= n_cand) arow = n_cand - 1;
+      bf16x8 af[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(E_b + arow * D + 16 * s + 8 * h);
+      if (h == 0) scores[r] = (item0 + r < n_cand) ? b[item0 + r] : NEG_INF_F;
+      __syncthreads();
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&scores[8 * q + 4 * h]);
+        acc[4 * q + 0] = t4.x;
+        acc[4 * q + 1] = t4.y;
+        acc[4 * q + 2] = t4.z;
+        acc[4 * q + 3] = t4.w;
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], hf[s], acc, 0, 0, 0);
+      __syncthreads();
+      if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) scores[mfma_row(i, h)] = acc[i];
+      }
+      __syncthreads();
+      bool valid = false;
+      uint64_t ck = 0;
+      if (lane < 32) {
+        const int64_t c = item0 + lane;
+        if (c < n_cand) {
+          const int32_t gid = item_ids ? item_ids[c] : (int32_t)c;
+          ck = make_key(scores[lane], (uint32_t)gid);
+          valid = !have_k || ck > tau;            // below the current k-th best: cannot enter the answer
+          if (valid && ns > 0) {                  // binary search in the user's ascending seen list
+            int lo = 0, hi = ns;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              const int32_t v = seen_in_lds ? seen_lds[mid] : seen_items[so + mid];
+              if (v < gid) lo = mid + 1; else hi = mid;
+            }
+            if (lo < ns && (seen_in_lds ? seen_lds[lo] : seen_items[so + lo]) == gid) valid = false;
+          }
+        }
+      }
+      const unsigned long long m = __ballot(valid);
+      if (valid) cand[ncand + __popcll(m & lt_mask)] = ck;
+      ncand += __popcll(m);
+      __syncthreads();
+    }
+  };
+
+  // ---- groups in (max desc, group asc) order until the next bound cannot beat tau ----------------------------------
+  int visited = 0;
+  for (;;) {
+    const uint64_t c1 = b1k ? (((uint64_t)b1k << 32) | (uint64_t)(~(uint32_t)(b1s * 64 + lane))) : 0ull;
+    const uint64_t cw = wave_max_u64(c1);
+    if (cw == 0) break;                                  // every group processed
+    const int g = (int)(~(uint32_t)(cw & 0xFFFFFFFFull));
+    if (have_k) {
+      const uint32_t gk = (uint32_t)(cw >> 32), tau_hi = (uint32_t)(tau >> 32);
+      bool beats = gk > tau_hi;
+      if (gk == tau_hi) {                                // tie on the score: the group's smallest item id decides
+        const int64_t c0 = (int64_t)g * tg * 32;
+        const uint32_t gid0 = (c0 < n_cand) ? (uint32_t)(item_ids ? item_ids[c0] : (int32_t)c0) : 0xFFFFFFFFu;
+        beats = (((uint64_t)gk << 32) | (uint64_t)(~gid0)) > tau;
+      }
+      if (!beats) break;
+    }
+    if (c1 == cw) {                                      // owner lane: pop
+      done |= 1ull << b1s;
+      b1k = b2k; b1s = b2s; b2k = 0;
+    }
+    // a lane that has handed out both of its bests may still hold the next one: refill (all lanes, rare)
+    const bool empty_but_more = (b1k == 0) && (__popcll(done) < nvalid);
+    if (__any(empty_but_more)) refill();
+    const int before = ncand;
+    rescore(g);
+    ++visited;
+    if (!have_k) {
+      if (visited >= k && ncand >= k) take_top_k();      // first estimate of tau after k groups
+    } else if (ncand > before) {
+      take_top_k();                                      // something beat tau: tighten it
+    }
+  }
+  take_top_k();
+  if (lane < ncand) {
+    const uint64_t ck = best[lane];
+    out_idx[u * k + lane] = (int32_t)(~(uint32_t)(ck & 0xFFFFFFFFull));
+    out_val[u * k + lane] = f32_from_order_key((uint32_t)(ck >> 32));
+  }
+  for (int i = ncand + lane; i < k; i += 64) {
+    out_idx[u * k + i] = -1;
+    out_val[u * k + i] = NEG_INF_F;
+  }
+  if (lane == 0) out_cnt[u] = ncand;
+}
+
+// =============================================================================================================
 static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 static int tk_tile_groups(int64_t n_cand, int* tg_out) {
@@ -410,14 +619,21 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
     if (k <= TK_CB_SMALL / 2) TK_LAUNCH_CB(DD, KP, TK_CB_SMALL); \
     else TK_LAUNCH_CB(DD, KP, TK_CB_LARGE);                   \
   } while (0)
-#define TK_BY_KPL(DD)                              \
-  do {                                             \
-    if (ngroups <= 1024) TK_LAUNCH(DD, 16);        \
-    else if (ngroups <= 2048) TK_LAUNCH(DD, 32);   \
-    else TK_LAUNCH(DD, 64);                        \
+#define TKS_LAUNCH(DD, KP)                                                                                          \
+  hipLaunchKernelGGL((topk_select_small_kernel<DD, KP>), grid, block, 0, s, H_b, n_users, E_b, b, n_cand, item_ids,  \
+                     seen_off, seen_items, seen_rows, (const float*)tm_t, gstride, ngroups, tg, k, out_idx, out_val,  \
+                     out_cnt)
+  static const int force_generic = getenv("CQL_TOPK_GENERIC") ? 1 : 0;   // tests run both kernels
+  const bool small_k = (k <= TKS_MAX_K) && !force_generic;
+#define TK_BY_KPL(DD)                                                       \
+  do {                                                                      \
+    if (ngroups <= 1024) { if (small_k) TKS_LAUNCH(DD, 16); else TK_LAUNCH(DD, 16); }      \
+    else if (ngroups <= 2048) { if (small_k) TKS_LAUNCH(DD, 32); else TK_LAUNCH(DD, 32); } \
+    else { if (small_k) TKS_LAUNCH(DD, 64); else TK_LAUNCH(DD, 64); }                      \
   } while (0)
   if (d == 64) TK_BY_KPL(64); else if (d == 128) TK_BY_KPL(128); else TK_BY_KPL(256);
 #undef TK_BY_KPL
+#undef TKS_LAUNCH
 #undef TK_LAUNCH
 #undef TK_LAUNCH_CB
   CQL_LAUNCH_CHECK("score_topk");

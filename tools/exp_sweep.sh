@@ -1,1 +1,1 @@
-for v in 2 4 2 4; do for tb in 512 768; do echo "== SPW=$v BLOCKS=$tb"; CQL_QS_BLOCKS=$tb CQL_QS_SPW_FWD=$v python tools/qhead_microbench.py --modes lse,argmax,topk --reps 10 2>&1 | grep -E "qhead_(lse|argmax)|tilemax"; done; done
+for v in "" 1 "" 1; do echo "== GENERIC=$v"; env ${v:+CQL_TOPK_GENERIC=1} python tools/qhead_microbench.py --modes topk --reps 10 2>&1 | grep -E "topk"; done
