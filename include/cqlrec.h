@@ -230,19 +230,29 @@ int cqlrec_train_step_backward_items(const cqlrec_train_ctx* ctx /* [host] */, u
 int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
 int cqlrec_train_step_update_range(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, int64_t lo, int64_t hi,
                                    cqlrec_stream stream);
+/* n_steps whole steps (steps step0 .. step0+n_steps-1) of a single-rank job (ctx->world == 1) in one call: the epoch
+ * loop of TorchRecommender.train (replay/models/base_torch_rec.py:78-84) without a host round trip per batch.
+ * Same dataflow and results as fwd_bwd + update per step, software-pipelined across the two halves of the model:
+ * Adam on E_in + encoder runs under the (MFMA-bound) item-side backward, the next step's sample / window gathers /
+ * encoder start while the item-side Adam is still running, and only the Q-head kernels wait for it.  Everything is
+ * joined on `stream` before the call returns.  loss_out: n_steps device floats (may be NULL). */
+int cqlrec_train_steps(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step0, int32_t n_steps, float* loss_out,
+                       cqlrec_stream stream);
 
 /* 1 (default; env CQL_CONCURRENCY=0 to disable): independent parts of a step (the sort for the gather backward, the
  * two forward branches, the item-side vs state-side Q-head backward) run on internal side streams, forked and joined
  * with events on `stream`.  0: strict program order on `stream` -- use it when timing individual kernels. */
 int cqlrec_set_concurrency(int32_t on);
 
-/* Debug/inspection of the step's intermediates inside ctx->ws (device pointers; valid after fwd_bwd). */
+/* Debug/inspection of the intermediates of step `step` inside ctx->ws (device pointers; valid after that step's
+ * fwd_bwd, until step+2 overwrites them: the per-step vectors are double-buffered by step parity). */
 typedef struct cqlrec_train_views {
   int32_t *users, *tpos, *act, *a_star;
   float *rew, *done, *q_a, *lse, *q_targ, *y, *coef, *dH, *dh0, *h0_s;
   uint16_t *hb_s, *hb_sn, *hb_tn;
 } cqlrec_train_views;
-int cqlrec_train_views_get(const cqlrec_train_ctx* ctx /* [host] */, cqlrec_train_views* out /* [host] */);
+int cqlrec_train_views_get(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step,
+                           cqlrec_train_views* out /* [host] */);
 
 /* ---------------------------------------------------------------------------------------------------------
  * f2  log -> CSR by user on the device: rows sorted by (user_idx, timestamp asc, item_idx asc), S2.  Takes the place of
@@ -286,7 +296,18 @@ enum {
   CQLREC_PH_GATHER_BWD, CQLREC_PH_ADAM, CQLREC_PH_TOPK_TILEMAX, CQLREC_PH_TOPK_SELECT, CQLREC_PH_COUNT
 };
 int cqlrec_prof_enable(int32_t on);
+/* Restrict the bracketing to the phases whose bit (1u << CQLREC_PH_*) is set; default: all.  Every event pair
+ * costs two barrier packets on its stream, so a throughput measurement brackets only the kernel it reports on. */
+int cqlrec_prof_select(uint32_t phase_mask);
 int cqlrec_prof_read(double* ms_sum /* [host] CQLREC_PH_COUNT */, int64_t* launches /* [host] CQLREC_PH_COUNT */);
+
+/* Schedule marks (tools/phase_timing.py): nine timing events at the joints of the middle step of a
+ * cqlrec_train_steps call (n_steps >= 4) -- loss, dH done, item-side backward done, encoder+gather backward done,
+ * Adam(E_in) done, Adam(E_out) done, next step's prologue done, its LSE done, its loss -- cheap enough not to disturb
+ * the overlap they measure.  marks_read synchronises and returns ms relative to the first mark (-1: not recorded). */
+#define CQLREC_DEBUG_MARKS 9
+int cqlrec_debug_marks_enable(int32_t on);
+int cqlrec_debug_marks_read(float* ms_out /* [host] CQLREC_DEBUG_MARKS */);
 
 #ifdef __cplusplus
 }

@@ -90,12 +90,16 @@ SIGNATURES = {
     "cqlrec_train_step_backward_rest": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),
     "cqlrec_set_concurrency": (i32, [i32]),
-    "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), C.POINTER(TrainViews)]),
+    "cqlrec_train_steps": (i32, [C.POINTER(TrainCtx), u64, i32, vp, vp]),
+    "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), u64, C.POINTER(TrainViews)]),
     "cqlrec_build_csr_ws_bytes": (i64, [i64]),
     "cqlrec_build_csr": (i32, [vp, vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]),
     "cqlrec_eval_topk_ws_bytes": (i64, [i64, i32]),
     "cqlrec_eval_topk": (i32, [vp, i64, i32, vp, vp, vp, C.POINTER(i32), i32, vp, i64, vp, vp, vp]),
     "cqlrec_prof_enable": (i32, [i32]),
+    "cqlrec_prof_select": (i32, [C.c_uint32]),
+    "cqlrec_debug_marks_enable": (i32, [i32]),
+    "cqlrec_debug_marks_read": (i32, [C.POINTER(C.c_float)]),
     "cqlrec_prof_read": (i32, [C.POINTER(C.c_double), C.POINTER(i64)]),
 }
 

@@ -177,6 +177,9 @@ class CQLCore:
         state-side backward, and Adam on that half overlaps the all-reduce of the rest (E_in + encoder)."""
         phased = (self.world > 1) if phased is None else phased
         if not phased:
+            if self.world == 1:
+                self.train_steps(1, loss_out)
+                return
             self.forward_backward(loss_out)
             self.allreduce_grads()
             self.apply_update()
@@ -188,13 +191,14 @@ class CQLCore:
             self._side = torch.cuda.Stream(device=self.device)
         side = self._side
         N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(loss_out), s), "train_step_forward")
-        # item-side backward (+ its all-reduce) on a side stream, concurrently with the state-side backward
         side.wait_stream(main)
+        # state-side backward on this stream: its dH kernel goes first; the item-side backward (+ its all-reduce), on
+        # the side stream, waits inside the library for that kernel and then runs under the encoder / gather backward
+        N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
         with torch.cuda.stream(side):
             N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
                     "train_step_backward_items")
             work_a = self._allreduce_async(self.grads[lo_a:hi_a])
-        N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
         work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
         if work_a is not None:
             work_a.wait()          # stream-side wait (RCCL): no host block
@@ -208,6 +212,17 @@ class CQLCore:
         N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, hi_a, total, s), "update_range")
         self.step += 1
 
+    def train_steps(self, n_steps: int, losses: Optional[torch.Tensor] = None) -> None:
+        """n_steps whole steps in ONE library call (single rank): the step loop runs in C++, software-pipelined across
+        steps (cqlrec_train_steps).  losses: optional device float tensor with >= n_steps elements."""
+        if self.world != 1:
+            raise RuntimeError("train_steps is the single-rank path; data-parallel jobs use train_step/train")
+        if losses is not None and (losses.numel() < n_steps or losses.dtype != torch.float32 or not losses.is_contiguous()):
+            raise ValueError("losses must be a contiguous float32 tensor with at least n_steps elements")
+        c = self._train_ctx()
+        N.check(self.lib.cqlrec_train_steps(C.byref(c), self.step, int(n_steps), _ptr(losses), _stream()), "train_steps")
+        self.step += int(n_steps)
+
     def _allreduce_async(self, t: torch.Tensor):
         if self.world <= 1:
             return None
@@ -218,6 +233,11 @@ class CQLCore:
         """n_steps CQL steps; returns the per-step (rank-local share of the) loss as a device tensor -- no host sync
         inside the loop (cf. loss.item() per step at replay/models/base_torch_rec.py:39)."""
         losses = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=self.device)
+        if self.world == 1 and not phased:
+            # chunks keep the host at most a few thousand launches ahead of the device
+            for lo in range(0, n_steps, 64):
+                self.train_steps(min(64, n_steps - lo), losses[lo:])
+            return losses[:n_steps]
         for i in range(n_steps):
             self.train_step(losses[i:i + 1], phased)
         if self.world > 1 and n_steps > 0:
@@ -249,11 +269,13 @@ class CQLCore:
             N.check(self.lib.cqlrec_train_step_forward(C.byref(c), i, _ptr(losses[i:i + 1]), _stream()), "eval forward")
         return float(losses[:n_batches].mean().item()) if n_batches else float("nan")
 
-    def views(self) -> Dict[str, torch.Tensor]:
-        """Intermediates of the last forward_backward (tests / debugging).  Copies, synchronises."""
+    def views(self, step: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Intermediates of step `step` (default: the current one, i.e. the last forward_backward before its
+        apply_update) -- tests / debugging.  Copies, synchronises."""
         c = self._train_ctx()
         v = N.TrainViews()
-        N.check(self.lib.cqlrec_train_views_get(C.byref(c), C.byref(v)), "train_views_get")
+        N.check(self.lib.cqlrec_train_views_get(C.byref(c), self.step if step is None else int(step), C.byref(v)),
+                "train_views_get")
         B, d = self.hyper.batch, self.hyper.d
         torch.cuda.synchronize(self.device)
         ws = self._ws

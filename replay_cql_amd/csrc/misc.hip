@@ -26,10 +26,11 @@ static struct {
   int phase[CQL_PROF_POOL];
   int n = 0;
   int open = -1;
+  uint32_t mask = 0xFFFFFFFFu;   // phases that are bracketed while on
 } g_prof;
 
 void cql_prof_begin(int phase, hipStream_t s) {
-  if (!g_prof.on || g_prof.n >= CQL_PROF_POOL) return;
+  if (!g_prof.on || g_prof.n >= CQL_PROF_POOL || !((g_prof.mask >> phase) & 1u)) return;
   g_prof.open = g_prof.n++;
   g_prof.phase[g_prof.open] = phase;
   (void)hipEventRecord(g_prof.ev[g_prof.open][0], s);
@@ -38,6 +39,10 @@ void cql_prof_end(hipStream_t s) {
   if (!g_prof.on || g_prof.open < 0) return;
   (void)hipEventRecord(g_prof.ev[g_prof.open][1], s);
   g_prof.open = -1;
+}
+extern "C" int cqlrec_prof_select(uint32_t phase_mask) {
+  g_prof.mask = phase_mask;
+  return CQLREC_OK;
 }
 extern "C" int cqlrec_prof_enable(int32_t on) {
   if (on && !g_prof.created) {

@@ -380,15 +380,21 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(dst + ft * 32 + 8 * q + 4 * h) =
-                make_float4(sc * y[g][ft][4 * q + 0], sc * y[g][ft][4 * q + 1], sc * y[g][ft][4 * q + 2],
-                            sc * y[g][ft][4 * q + 3]);
+          for (int q = 0; q < 4; ++q) {
+            float4* pd = reinterpret_cast<float4*>(dst + ft * 32 + 8 * q + 4 * h);
+            float4 o = make_float4(sc * y[g][ft][4 * q + 0], sc * y[g][ft][4 * q + 1], sc * y[g][ft][4 * q + 2],
+                                   sc * y[g][ft][4 * q + 3]);
+            if (a.out && a.accumulate) {
+              const float4 old = *pd;
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *pd = o;
+          }
       }
       if constexpr (MODE == QM_BWD_DE) {
         const float cs = st_b[g] + __shfl_xor(st_b[g], 32);
         if (ok && h == 0) {
-          if (a.out) a.out_cs[row] = sc * cs;
+          if (a.out) a.out_cs[row] = a.accumulate ? a.out_cs[row] + sc * cs : sc * cs;
           else a.slab_cs[pidx] = cs;
         }
       }
@@ -561,7 +567,8 @@ __global__ __launch_bounds__(256) void qhead_bwd_reduce_kernel(const float* __re
                                                                const float* __restrict__ coef,
                                                                const int32_t* __restrict__ act,
                                                                const uint16_t* __restrict__ E_b,
-                                                               float* __restrict__ dst, float* __restrict__ cs_dst) {
+                                                               float* __restrict__ dst, float* __restrict__ cs_dst,
+                                                               int accumulate) {
   constexpr int V = D / 4;  // float4 per row
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * V) return;
@@ -587,11 +594,15 @@ __global__ __launch_bounds__(256) void qhead_bwd_reduce_kernel(const float* __re
     s.z = fmaf(cf, __uint_as_float(e.y << 16), s.z);
     s.w = fmaf(cf, __uint_as_float(e.y & 0xFFFF0000u), s.w);
   }
+  if (accumulate) {
+    const float4 old = *reinterpret_cast<const float4*>(dst + row * D + c * 4);
+    s.x += old.x; s.y += old.y; s.z += old.z; s.w += old.w;
+  }
   *reinterpret_cast<float4*>(dst + row * D + c * 4) = s;
   if (slab_cs && c == 0) {
     float t = 0.f;
     for (int k = 0; k < nsplit; ++k) t += slab_cs[(int64_t)k * rows + row];
-    cs_dst[row] = t * scale;
+    cs_dst[row] = accumulate ? cs_dst[row] + t * scale : t * scale;
   }
 }
 
@@ -703,7 +714,7 @@ extern "C" int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, 
   dim3 grid(cql_ceil_div(n4, 256)), block(256);
 #define RED_DH(DD)                                                                                                  \
   hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, (const float*)nullptr, a.nsplit, batch, \
-                     scale, coef, act, E_out_b, dH, (float*)nullptr)
+                     scale, coef, act, E_out_b, dH, (float*)nullptr, 0)
   if (d == 64) RED_DH(64); else if (d == 128) RED_DH(128); else RED_DH(256);
 #undef RED_DH
   CQL_LAUNCH_CHECK("qhead_bwd_states");
@@ -711,16 +722,24 @@ extern "C" int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, 
 }
 
 // g_E_out / g_b_out only (owner = items, streamed = states)
-extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
-                                      int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
-                                      int32_t d, float scale, void* ws, int64_t ws_bytes, float* g_E_out,
-                                      float* g_b_out, cqlrec_stream stream) {
+static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                               int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
+                               float scale, void* ws, int64_t ws_bytes, float* g_E_out, float* g_b_out,
+                               cqlrec_stream stream, bool sparse_first) {
   CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && g_E_out && g_b_out, "qhead_bwd_items: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_bwd_items: d=%d unsupported", d);
   CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd_items: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
   CQL_REQUIRE(ws_bytes >= cqlrec_qhead_bwd_ws_bytes(batch, n_items, d), "qhead_bwd_items: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
+  auto launch_sparse = [&]() {
+    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+    dim3 g2(cql_ceil_div(batch, 4));
+#define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
+    if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);
+#undef SP_DE
+  };
+  if (sparse_first) launch_sparse();
   // Large catalogues: one block per 128 items streams every state and writes its rows directly (no cross-block
   // sum).  Small catalogues: the state axis is split too, slabs are summed by the small reduce kernel.  (A third
   // variant -- a whole number of resident "rounds" first, the remainder with split states -- measured no faster:
@@ -747,6 +766,7 @@ extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, c
       a.out = g_E_out + row0 * d;
       a.out_cs = g_b_out + row0;
       a.scale = scale;
+      a.accumulate = sparse_first ? 1 : 0;
     }
     qs_launch(QM_BWD_DE, a, d, sp.rblks, s);
     if (!direct) {
@@ -756,20 +776,31 @@ extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, c
 #define RED_DE(DD)                                                                                            \
   hipLaunchKernelGGL(qhead_bwd_reduce_kernel<DD>, grid, block, 0, s, a.slab, a.slab_cs, a.nsplit, count, scale, \
                      (const float*)nullptr, (const int32_t*)nullptr, (const uint16_t*)nullptr,                 \
-                     g_E_out + row0 * d, g_b_out + row0)
+                     g_E_out + row0 * d, g_b_out + row0, sparse_first ? 1 : 0)
       if (d == 64) RED_DE(64); else if (d == 128) RED_DE(128); else RED_DE(256);
 #undef RED_DE
     }
   };
   const int64_t rblks_all = (n_items + 127) / 128;
   launch_range(0, n_items, rblks_all >= QS_TARGET_BLOCKS_BWD);
-  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
-  dim3 g2(cql_ceil_div(batch, 4));
-#define SP_DE(DD) hipLaunchKernelGGL(qhead_bwd_sparse_kernel<DD>, g2, block, 0, s, coef, act, H_b, batch, g_E_out, g_b_out)
-  if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);
-#undef SP_DE
+  if (!sparse_first) launch_sparse();
   CQL_LAUNCH_CHECK("qhead_bwd_items");
   return CQLREC_OK;
+}
+
+extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
+                                      int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                                      int32_t d, float scale, void* ws, int64_t ws_bytes, float* g_E_out,
+                                      float* g_b_out, cqlrec_stream stream) {
+  return qhead_bwd_items_impl(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
+                              g_b_out, stream, false);
+}
+
+int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
+                            const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
+                            int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream) {
+  return qhead_bwd_items_impl(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
+                              g_b_out, (cqlrec_stream)stream, true);
 }
 
 extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,

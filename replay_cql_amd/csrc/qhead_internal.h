@@ -35,6 +35,7 @@ struct QArgs {
   float* out;
   float* out_cs;
   float scale;
+  int accumulate;            // direct output adds to out / out_cs instead of overwriting (rows are block-owned: no atomics)
 };
 
 struct QSplit {
@@ -46,3 +47,8 @@ struct QSplit {
 int qs_spw_fwd(int d);
 QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int target_blocks);
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
+// item-side backward for the step driver: the one-hot scatter goes FIRST (into zeroed g_E_out / g_b_out), the streaming
+// kernel then adds its rows -- nothing small is left behind the long kernel on the step's critical path.
+int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
+                            const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
+                            int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream);

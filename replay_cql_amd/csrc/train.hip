@@ -3,8 +3,37 @@
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
+#include "qhead_internal.h"
 
 static int g_concurrency = -1;   // -1: read CQL_CONCURRENCY on first use (default on)
+
+// ---- schedule marks (tools/phase_timing.py): a handful of timing events at the joints of ONE step of a
+// cqlrec_train_steps call -- cheap enough not to disturb the overlap they measure (unlike bracketing every kernel)
+enum { MK_LOSS = 0, MK_DH, MK_DE, MK_CHAIN, MK_ADAM_IN, MK_ADAM_OUT, MK_PROLOGUE, MK_LSE, MK_NEXT_LOSS, MK_COUNT };
+static hipEvent_t g_marks[MK_COUNT];
+static int g_marks_on = 0;       // cqlrec_debug_marks_enable
+static int g_mark_phase = 0;     // 1: backward of the marked step, 2: forward of the step after it
+static void mark(int k, hipStream_t s) {
+  if (g_marks_on && g_mark_phase) (void)hipEventRecord(g_marks[k], s);
+}
+extern "C" int cqlrec_debug_marks_enable(int32_t on) {
+  if (on && !g_marks[0])
+    for (int i = 0; i < MK_COUNT; ++i)
+      if (hipEventCreate(&g_marks[i]) != hipSuccess) return CQLREC_ERR_HIP;
+  g_marks_on = on ? 1 : 0;
+  return CQLREC_OK;
+}
+// ms of each mark relative to MK_LOSS (device must be idle: synchronises); order as the enum above
+extern "C" int cqlrec_debug_marks_read(float* ms_out) {
+  if (!g_marks[0] || !ms_out) return CQLREC_ERR_INVALID;
+  for (int i = 0; i < MK_COUNT; ++i) {
+    ms_out[i] = -1.f;
+    if (hipEventSynchronize(g_marks[i]) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_marks[MK_LOSS], g_marks[i]) == hipSuccess) ms_out[i] = ms;
+  }
+  return CQLREC_OK;
+}
 
 namespace {
 struct Carve {
@@ -29,9 +58,9 @@ struct StepWs {
   int64_t total;
 };
 
-StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L) {
-  StepWs w;
-  Carve c(ws);
+// The per-step vectors and activations exist twice (parity = step & 1): cqlrec_train_steps starts the prologue of step
+// t+1 (sample, gathers, encoder) while the item-side backward of step t still reads act / coef / nlse2 / hb of step t.
+void carve_small(Carve& c, StepWs& w, int32_t B, int32_t d) {
   w.users = c.take<int32_t>(B);
   w.tpos = c.take<int32_t>(B);
   w.act = c.take<int32_t>(B);
@@ -55,6 +84,18 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L) {
   w.h0b_t = c.take<uint16_t>((int64_t)B * d);
   w.zb_t = c.take<uint16_t>((int64_t)B * d);
   w.hb_t = c.take<uint16_t>((int64_t)B * d);
+}
+
+StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L, uint64_t step = 0) {
+  StepWs w, other;
+  Carve c(ws);
+  if (step & 1) {
+    carve_small(c, other, B, d);
+    carve_small(c, w, B, d);
+  } else {
+    carve_small(c, w, B, d);
+    carve_small(c, other, B, d);
+  }
   w.ws_q_bytes = cqlrec_qhead_ws_bytes(B, N, d);
   w.ws_q = c.take<char>(w.ws_q_bytes);     // LSE partials (branch A)
   w.ws_q2 = c.take<char>(w.ws_q_bytes);    // ARGMAX partials (branch B runs concurrently)
@@ -64,7 +105,9 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L) {
   w.ws_enc_bytes = cqlrec_encoder_bwd_ws_bytes(B, d);
   w.ws_enc = c.take<char>(w.ws_enc_bytes);
   w.ws_gb_bytes = cqlrec_gather_pool_bwd_ws_bytes(B, L, d);
-  w.ws_gb = c.take<char>(w.ws_gb_bytes);
+  void* gb0 = c.take<char>(w.ws_gb_bytes);   // sorted (item, state) pairs: by parity as well, the sort of step t+1 is
+  void* gb1 = c.take<char>(w.ws_gb_bytes);   // issued while the gather backward of step t has not run yet
+  w.ws_gb = (step & 1) ? gb1 : gb0;
   w.total = c.off;
   return w;
 }
@@ -109,6 +152,7 @@ struct SideStream {
   hipStream_t s = nullptr;    // sort of the gather backward (forward phase), item-side backward (backward phase)
   hipStream_t s2 = nullptr;   // branch B of the forward (s' rows: argmax + target network)
   hipEvent_t forked = nullptr, joined = nullptr, fork2 = nullptr, join2 = nullptr;
+  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr;
   bool ok = false;
   bool tried = false;
 };
@@ -125,12 +169,25 @@ SideStream& side_stream() {
   if (!concurrency_on()) return off;
   if (!ss.tried) {
     ss.tried = true;
-    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
+    // Queue priorities steer what the dispatcher does when two long kernels compete: the item-side backward (stream s)
+    // yields to the caller's stream, so that the state-side kernel finishes first and the chain behind it (encoder and
+    // gather backward, Adam on E_in) runs under the rest of the item-side kernel; the branch stream s2 carries small
+    // latency-critical launches and goes first.  CQL_STREAM_PRIO=0 creates plain streams.
+    int least = 0, greatest = 0;
+    const char* pv = getenv("CQL_STREAM_PRIO");
+    if (!(pv && *pv == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    if (pv && *pv == '0') least = greatest = 0;
+    ss.ok = hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, least) == hipSuccess &&
+            hipStreamCreateWithPriority(&ss.s2, hipStreamNonBlocking, greatest) == hipSuccess &&
             hipEventCreateWithFlags(&ss.forked, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.joined, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.fork2, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.loss, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.items, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.dh, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.eout, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.presample, hipEventDisableTiming) == hipSuccess;
   }
   return ss;
 }
@@ -152,32 +209,55 @@ StepPtrs step_ptrs(const cqlrec_train_ctx* c) {
 }
 }  // namespace
 
-// phase 1: sample + forward + loss (+ the sort for the gather backward, forked onto the side stream)
-extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
-                                         cqlrec_stream stream) {
-  CQL_TRY(check_ctx(c));
+#define CQL_HIP_TRY(expr, what)                 \
+  do {                                          \
+    if ((expr) != hipSuccess) {                 \
+      cql_set_error("%s: %s failed", what, #expr); \
+      return CQLREC_ERR_HIP;                    \
+    }                                           \
+  } while (0)
+
+namespace {
+// sample + forward + loss (+ the sort for the gather backward, forked onto the side stream).  `eout_ready`: event
+// after which the item-side parameters (E_out, b_out and their shadows) are up to date -- everything before the
+// Q-head kernels (sample, window gathers, encoder) reads only E_in / W1 / W2 and may start earlier.
+// `presampled`: event after which this step's transitions and sorted pairs are already in place (sample_ahead).
+int sample_ahead(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  const cqlrec_layout& L = c->layout;
+  StepWs w = carve_step(c->ws, c->batch, L.n_items, L.d, c->window, step);
+  CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
+                                    (uint64_t)c->rank * (uint64_t)c->batch, c->batch, w.users, w.tpos, w.act, w.rew,
+                                    w.done, stream));
+  return cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, c->batch, c->window, L.d, L.n_items,
+                                        w.ws_gb, w.ws_gb_bytes, stream);
+}
+
+int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlrec_stream stream, hipEvent_t eout_ready,
+                 hipEvent_t presampled = nullptr) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d, W = c->window;
   const int64_t N = L.n_items;
-  StepWs w = carve_step(c->ws, B, N, d, W);
+  StepWs w = carve_step(c->ws, B, N, d, W, step);
   const StepPtrs p = step_ptrs(c);
   const int64_t Bd = (int64_t)B * d;
   hipStream_t s = (hipStream_t)stream;
 
-  // transitions of this rank's slots of the global step
-  CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
-                                    (uint64_t)c->rank * (uint64_t)B, B, w.users, w.tpos, w.act, w.rew, w.done, stream));
   SideStream& ss = side_stream();
-  if (ss.ok) {
-    if (hipEventRecord(ss.forked, s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.forked, 0) != hipSuccess) ss.ok = false;
+  if (presampled) {
+    CQL_HIP_TRY(hipStreamWaitEvent(s, presampled, 0), "train_step_forward");
+  } else {
+    // transitions of this rank's slots of the global step
+    CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
+                                      (uint64_t)c->rank * (uint64_t)B, B, w.users, w.tpos, w.act, w.rew, w.done, stream));
+    if (ss.ok) {
+      if (hipEventRecord(ss.forked, s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.forked, 0) != hipSuccess) ss.ok = false;
+    }
   }
-  if (ss.ok) {
+  if (presampled) {
+  } else if (ss.ok) {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            (cqlrec_stream)ss.s));
-    if (hipEventRecord(ss.joined, ss.s) != hipSuccess) {
-      cql_set_error("train_step_forward: hipEventRecord failed");
-      return CQLREC_ERR_HIP;
-    }
+    CQL_HIP_TRY(hipEventRecord(ss.joined, ss.s), "train_step_forward");
   } else {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            stream));
@@ -193,7 +273,10 @@ extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t ste
   CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, w.h0_s, w.h0b, nullptr, stream));
   CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, B, d, 1, nullptr, w.zb, stream));
   CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, B, d, 0, nullptr, w.hb, stream));
+  if (g_mark_phase == 2) mark(MK_PROLOGUE, s);
+  if (eout_ready) CQL_HIP_TRY(hipStreamWaitEvent(s, eout_ready, 0), "train_step_forward");
   CQL_TRY(cqlrec_qhead_fwd(w.hb, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_LSE, w.ws_q, w.ws_q_bytes, w.lse, nullptr, w.nlse2, stream));
+  if (g_mark_phase == 2) mark(MK_LSE, s);
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
   CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, sb));
@@ -202,6 +285,7 @@ extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t ste
   CQL_TRY(cqlrec_linear_bf16(w.zb + Bd, p.W2_b, p.b2, B, d, 0, nullptr, w.hb + Bd, sb));
   CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, sb));
   CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, sb));
+  if (eout_ready && par) CQL_HIP_TRY(hipStreamWaitEvent(ss.s2, eout_ready, 0), "train_step_forward");
   CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star, nullptr, sb));
   CQL_TRY(cqlrec_gather_dot(w.hb_t, p.tEout_b, p.tb_out, w.a_star, B, d, w.q_targ, sb));
   if (par && (hipEventRecord(ss.join2, ss.s2) != hipSuccess || hipStreamWaitEvent(s, ss.join2, 0) != hipSuccess)) {
@@ -212,75 +296,156 @@ extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t ste
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
   CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, c->gamma, c->alpha, inv_batch, w.coef, w.y,
                          loss_out ? loss_out : w.loss, stream));
+  if (g_mark_phase == 2) mark(MK_NEXT_LOSS, s);
   return CQLREC_OK;
+}
+
+// The two halves of the Q-head backward are both MFMA-bound: run together they just share the chip and finish
+// together, and the chain behind the state side (encoder + gather backward, Adam on E_in: HBM / latency bound) would
+// start only then.  So the state-side kernel goes first with the chip to itself (512 blocks = one full round at cfg3)
+// and the item-side kernel, on its own stream, starts when it is done (event `dh`) and runs UNDER that chain.
+int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  const cqlrec_layout& L = c->layout;
+  const int32_t B = c->batch, d = L.d;
+  SideStream& ss = side_stream();
+  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.dh, 0), "train_step_backward_items");
+  StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
+  const StepPtrs p = step_ptrs(c);
+  const float inv_batch = 1.0f / ((float)B * (float)c->world);
+  // ctx->grads is zero on entry (contract of the step): scatter first, the streaming kernel accumulates
+  return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
+                                 w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
+                                 (hipStream_t)stream);
+}
+
+// records `dh` behind the dH kernel: the item-side backward waits for it (see above), and so does the item-side Adam
+// (dH is the last reader of the E_out shadow on this stream)
+int backward_states_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  const cqlrec_layout& L = c->layout;
+  const int32_t B = c->batch, d = L.d;
+  const int64_t N = L.n_items;
+  StepWs w = carve_step(c->ws, B, N, d, c->window, step);
+  const StepPtrs p = step_ptrs(c);
+  const float inv_batch = 1.0f / ((float)B * (float)c->world);
+  CQL_TRY(cqlrec_qhead_bwd_states(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, N, d, c->alpha * inv_batch, w.ws_qb,
+                                  w.ws_qb_bytes, w.dH, stream));
+  SideStream& ss = side_stream();
+  if (ss.ok) CQL_HIP_TRY(hipEventRecord(ss.dh, (hipStream_t)stream), "train_step_backward_rest");
+  return CQLREC_OK;
+}
+
+// the chain behind dH: encoder backward, window-gather backward
+int backward_chain_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  const cqlrec_layout& L = c->layout;
+  const int32_t B = c->batch, d = L.d, W = c->window;
+  const int64_t N = L.n_items;
+  StepWs w = carve_step(c->ws, B, N, d, W, step);
+  const StepPtrs p = step_ptrs(c);
+  CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
+                             c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
+  SideStream& ss = side_stream();
+  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.joined, 0), "train_step_backward_rest");
+  CQL_TRY(cqlrec_gather_pool_bwd_apply(w.dh0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, c->grads + L.off_E_in, stream));
+  return CQLREC_OK;
+}
+
+int backward_rest_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  CQL_TRY(backward_states_impl(c, step, stream));
+  return backward_chain_impl(c, step, stream);
+}
+}  // namespace
+
+// phase 1: sample + forward + loss (+ the sort for the gather backward, forked onto the side stream)
+extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
+                                         cqlrec_stream stream) {
+  CQL_TRY(check_ctx(c));
+  return forward_impl(c, step, loss_out, stream, nullptr);
 }
 
 // phase 2: the catalogue-side gradients g_E_out, g_b_out (half of the gradient bytes; a data-parallel caller starts
 // their all-reduce while phase 3 runs)
 extern "C" int cqlrec_train_step_backward_items(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
-  (void)step;
   CQL_TRY(check_ctx(c));
-  const cqlrec_layout& L = c->layout;
-  const int32_t B = c->batch, d = L.d;
-  StepWs w = carve_step(c->ws, B, L.n_items, d, c->window);
-  const StepPtrs p = step_ptrs(c);
-  const float inv_batch = 1.0f / ((float)B * (float)c->world);
-  return cqlrec_qhead_bwd_items(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
-                                w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out, stream);
+  return backward_items_impl(c, step, stream);
 }
 
 // phase 3: dH, encoder backward, window-gather backward (joins the side stream)
 extern "C" int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
-  (void)step;
   CQL_TRY(check_ctx(c));
-  const cqlrec_layout& L = c->layout;
-  const int32_t B = c->batch, d = L.d, W = c->window;
-  const int64_t N = L.n_items;
-  StepWs w = carve_step(c->ws, B, N, d, W);
-  const StepPtrs p = step_ptrs(c);
-  const float inv_batch = 1.0f / ((float)B * (float)c->world);
-  CQL_TRY(cqlrec_qhead_bwd_states(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, N, d, c->alpha * inv_batch, w.ws_qb,
-                                  w.ws_qb_bytes, w.dH, stream));
-  CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
-                             c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
-  SideStream& ss = side_stream();
-  if (ss.ok && hipStreamWaitEvent((hipStream_t)stream, ss.joined, 0) != hipSuccess) {
-    cql_set_error("train_step_backward_rest: hipStreamWaitEvent failed");
-    return CQLREC_ERR_HIP;
-  }
-  CQL_TRY(cqlrec_gather_pool_bwd_apply(w.dh0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, c->grads + L.off_E_in, stream));
-  return CQLREC_OK;
+  return backward_rest_impl(c, step, stream);
 }
 
 extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
                                          cqlrec_stream stream) {
   CQL_TRY(cqlrec_train_step_forward(c, step, loss_out, stream));
-  // The item-side and the state-side halves of the Q-head backward are independent.  Each alone leaves part of the
-  // chip idle in its last "round" of resident blocks (782 resp. 512 blocks on 512 slots at cfg3); issued on two
-  // streams, the hardware scheduler packs them.  Fork after the loss, join before returning.
   SideStream& ss = side_stream();
   hipStream_t s = (hipStream_t)stream;
-  static hipEvent_t ev_loss = nullptr, ev_items = nullptr;
-  if (ss.ok && !ev_loss) {
-    if (hipEventCreateWithFlags(&ev_loss, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_items, hipEventDisableTiming) != hipSuccess)
-      ss.ok = false;
-  }
-  if (ss.ok && hipEventRecord(ev_loss, s) == hipSuccess && hipStreamWaitEvent(ss.s, ev_loss, 0) == hipSuccess) {
-    CQL_TRY(cqlrec_train_step_backward_items(c, step, (cqlrec_stream)ss.s));
-    if (hipEventRecord(ev_items, ss.s) != hipSuccess) {
-      cql_set_error("train_step_fwd_bwd: hipEventRecord failed");
-      return CQLREC_ERR_HIP;
-    }
-    CQL_TRY(cqlrec_train_step_backward_rest(c, step, stream));
-    if (hipStreamWaitEvent(s, ev_items, 0) != hipSuccess) {
-      cql_set_error("train_step_fwd_bwd: hipStreamWaitEvent failed");
-      return CQLREC_ERR_HIP;
-    }
+  CQL_TRY(backward_states_impl(c, step, stream));                        // dH first, records ss.dh behind it
+  if (ss.ok) {
+    CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));          // waits for ss.dh, runs under the chain
+    CQL_HIP_TRY(hipEventRecord(ss.items, ss.s), "train_step_fwd_bwd");
+    CQL_TRY(backward_chain_impl(c, step, stream));
+    CQL_HIP_TRY(hipStreamWaitEvent(s, ss.items, 0), "train_step_fwd_bwd");
     return CQLREC_OK;
   }
-  CQL_TRY(cqlrec_train_step_backward_items(c, step, stream));
-  return cqlrec_train_step_backward_rest(c, step, stream);
+  CQL_TRY(backward_chain_impl(c, step, stream));
+  return backward_items_impl(c, step, stream);
+}
+
+// n_steps whole steps (sample .. Adam) of a single-rank job, software-pipelined across the two halves of the model:
+//   * side stream: item-side backward (dE_out, db_out) of step t, then Adam on the E_out/b_out range;
+//   * main stream: state-side backward (dH, encoder, window gather) of step t, then Adam on E_in + encoder -- HBM-bound,
+//     it runs under the MFMA-bound item-side kernel -- then ALREADY the prologue of step t+1 (sample, window gathers,
+//     encoder: they read only E_in / W), which waits for the item-side Adam only in front of its Q-head kernels.
+// Same dataflow as fwd_bwd + update per step; joined before returning.  world must be 1 (no all-reduce in here).
+extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int32_t n_steps, float* loss_out,
+                                  cqlrec_stream stream) {
+  CQL_TRY(check_ctx(c));
+  CQL_REQUIRE(n_steps >= 0, "train_steps: n_steps=%d", n_steps);
+  CQL_REQUIRE(c->world == 1, "train_steps: world=%d; data-parallel callers use the phase entry points", c->world);
+  const cqlrec_layout& L = c->layout;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t pending = nullptr;   // item-side Adam of the previous step
+  hipEvent_t sampled = nullptr;   // transitions + sorted pairs of this step, prepared during the previous backward
+  for (int32_t i = 0; i < n_steps; ++i) {
+    const uint64_t step = step0 + (uint64_t)i;
+    CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled));
+    pending = sampled = nullptr;
+    if (g_marks_on && n_steps >= 4) {   // marks: backward of step n/2, forward of step n/2 + 1
+      if (i == n_steps / 2) g_mark_phase = 1;
+      else if (i == n_steps / 2 + 1) g_mark_phase = 0;
+    }
+    SideStream& ss = side_stream();
+    if (g_mark_phase == 1) mark(MK_LOSS, s);
+    if (ss.ok && hipEventRecord(ss.loss, s) == hipSuccess) {
+      if (i + 1 < n_steps && hipStreamWaitEvent(ss.s2, ss.loss, 0) == hipSuccess) {
+        // the next step's transitions depend on (seed, step) only: sample and sort them on the idle branch stream now
+        CQL_TRY(sample_ahead(c, step + 1, (cqlrec_stream)ss.s2));
+        CQL_HIP_TRY(hipEventRecord(ss.presample, ss.s2), "train_steps");
+        sampled = ss.presample;
+      }
+      CQL_TRY(backward_states_impl(c, step, stream));                      // dH, records ss.dh
+      if (g_mark_phase == 1) mark(MK_DH, s);
+      CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));          // waits for ss.dh
+      if (g_mark_phase == 1) mark(MK_DE, ss.s);
+      CQL_TRY(cqlrec_train_step_update_range(c, step, L.off_E_out, L.off_W1, (cqlrec_stream)ss.s));
+      if (g_mark_phase == 1) mark(MK_ADAM_OUT, ss.s);
+      CQL_TRY(backward_chain_impl(c, step, stream));                       // encoder, window gather
+      if (g_mark_phase == 1) mark(MK_CHAIN, s);
+      CQL_TRY(cqlrec_train_step_update_range(c, step, L.off_W1, L.total, stream));
+      CQL_TRY(cqlrec_train_step_update_range(c, step, 0, L.off_E_out, stream));
+      if (g_mark_phase == 1) { mark(MK_ADAM_IN, s); g_mark_phase = 2; }
+      CQL_HIP_TRY(hipEventRecord(ss.eout, ss.s), "train_steps");
+      pending = ss.eout;
+    } else {
+      CQL_TRY(backward_rest_impl(c, step, stream));
+      CQL_TRY(backward_items_impl(c, step, stream));
+      CQL_TRY(cqlrec_train_step_update_range(c, step, 0, L.total, stream));
+    }
+  }
+  g_mark_phase = 0;
+  if (pending) CQL_HIP_TRY(hipStreamWaitEvent(s, pending, 0), "train_steps");
+  return CQLREC_OK;
 }
 
 // Adam + target + shadows (+ zero grads) over elements [lo, hi) of the flat buffers (multiples of 4)
@@ -303,11 +468,11 @@ extern "C" int cqlrec_train_step_update(const cqlrec_train_ctx* c, uint64_t step
   return cqlrec_train_step_update_range(c, step, 0, c->layout.total, stream);
 }
 
-extern "C" int cqlrec_train_views_get(const cqlrec_train_ctx* c, cqlrec_train_views* out) {
+extern "C" int cqlrec_train_views_get(const cqlrec_train_ctx* c, uint64_t step, cqlrec_train_views* out) {
   CQL_TRY(check_ctx(c));
   CQL_REQUIRE(out != nullptr, "train_views_get: out is NULL");
   const int32_t B = c->batch, d = c->layout.d;
-  StepWs w = carve_step(c->ws, B, c->layout.n_items, d, c->window);
+  StepWs w = carve_step(c->ws, B, c->layout.n_items, d, c->window, step);
   out->users = w.users; out->tpos = w.tpos; out->act = w.act; out->a_star = w.a_star;
   out->rew = w.rew; out->done = w.done; out->q_a = w.q_a; out->lse = w.lse; out->q_targ = w.q_targ;
   out->y = w.y; out->coef = w.coef; out->dH = w.dH; out->dh0 = w.dh0; out->h0_s = w.h0_s;

@@ -98,6 +98,37 @@ def test_training_trajectory(U, Nn, d, B, L, steps):
     assert np.array_equal(bf16_to_np(core.theta_b), O.bf16_round(th))
 
 
+def test_pipelined_steps_match_step_by_step():
+    """cqlrec_train_steps (Adam halves under the backward, next prologue under the item-side Adam, double-buffered
+    step vectors) computes the same steps as fwd_bwd + update one at a time in strict program order."""
+    from replay_cql_amd import _native as N
+    U, Nn, d, B, L, steps = 300, 1000, 128, 256, 8, 7
+    _, a, _ = _make(U, Nn, d, B, L)
+    _, b, _ = _make(U, Nn, d, B, L)
+    la = torch.zeros(steps, device=DEV)
+    a.train_steps(3, la)
+    a.train_steps(steps - 3, la[3:])
+    lb = torch.zeros(steps, device=DEV)
+    N.check(N.load().cqlrec_set_concurrency(0))
+    try:
+        for i in range(steps):
+            b.forward_backward(lb[i:i + 1])
+            b.apply_update()
+    finally:
+        N.check(N.load().cqlrec_set_concurrency(1))
+    torch.cuda.synchronize()
+    assert a.step == b.step == steps
+    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-5)
+    # float atomics (one-hot scatter, run edges of the gather backward) make the last bits order dependent
+    np.testing.assert_allclose(a.theta.cpu().numpy(), b.theta.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(a.target.cpu().numpy(), b.target.cpu().numpy(), atol=2e-6)
+    assert np.count_nonzero(a.grads.cpu().numpy()) == 0
+    # views of a given step stay addressable by parity
+    v = a.views(steps - 1)
+    pos = O.sample_positions(11, steps - 1, 0, B, int(a._csr[0][-1]))
+    assert np.array_equal(v["tpos"].cpu().numpy(), O.positions_to_transitions(pos, a._csr[0].cpu().numpy())[1])
+
+
 def test_core_predict_matches_oracle():
     U, Nn, d, L, k = 150, 2000, 128, 10, 10
     m, core, (off, items, rew) = _make(U, Nn, d, 128, L)
