@@ -1,5 +1,6 @@
 // Sampler, window gather (+backward), encoder layers (+backward), TD loss, gather-dot, fused Adam.
 // gfx950 only.  Algorithmic bytes per unit are listed in DESIGN.md.
+#include <stdlib.h>
 #include "common.h"
 
 // =============================================================================================================
@@ -597,6 +598,33 @@ extern "C" int cqlrec_td_loss(const float* q_a, const float* lse, const float* q
 // fused Adam + Polyak + bf16 shadows.  Pure HBM streaming: 20 B read + 24 B written per parameter.
 // Compiled with -ffp-contract=off so the expression order below is the normative one (oracle.adam_ema_step).
 // =============================================================================================================
+// NT: the fp32 streams (read once, written once per step) bypass the caches with non-temporal accesses, so that this
+// kernel does not evict the bf16 E_out shadow -- which the Q-head kernels keep re-reading from L2 / Infinity Cache --
+// when it runs next to them; the bf16 shadows it writes stay cacheable (they are what the next kernels read).
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4* p) {
+  if constexpr (NT) {
+    const float* f = reinterpret_cast<const float*>(p);
+    return make_float4(__builtin_nontemporal_load(f), __builtin_nontemporal_load(f + 1), __builtin_nontemporal_load(f + 2),
+                       __builtin_nontemporal_load(f + 3));
+  } else {
+    return *p;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float4* p, float a, float b, float c, float d) {
+  if constexpr (NT) {
+    float* f = reinterpret_cast<float*>(p);
+    __builtin_nontemporal_store(a, f);
+    __builtin_nontemporal_store(b, f + 1);
+    __builtin_nontemporal_store(c, f + 2);
+    __builtin_nontemporal_store(d, f + 3);
+  } else {
+    *p = make_float4(a, b, c, d);
+  }
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ theta, float4* __restrict__ grads,
                                                        float4* __restrict__ m, float4* __restrict__ v,
                                                        float4* __restrict__ target, uint2* __restrict__ theta_b,
@@ -605,8 +633,8 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ thet
                                                        int zero_grads) {
   const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2, omt = 1.0f - tau;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 g4 = grads[i];
-    float4 p4 = theta[i], m4 = m[i], v4 = v[i], t4 = target[i];
+    const float4 g4 = ld4<NT>(grads + i);
+    float4 p4 = ld4<NT>(theta + i), m4 = ld4<NT>(m + i), v4 = ld4<NT>(v + i), t4 = ld4<NT>(target + i);
     const float g[4] = {g4.x, g4.y, g4.z, g4.w};
     float p[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w},
           tt[4] = {t4.x, t4.y, t4.z, t4.w};
@@ -618,13 +646,13 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ thet
       p[k] = p[k] - step_size * (mm[k] / denom);
       tt[k] = omt * tt[k] + tau * p[k];
     }
-    theta[i] = make_float4(p[0], p[1], p[2], p[3]);
-    m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    v[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    target[i] = make_float4(tt[0], tt[1], tt[2], tt[3]);
+    st4<NT>(theta + i, p[0], p[1], p[2], p[3]);
+    st4<NT>(m + i, mm[0], mm[1], mm[2], mm[3]);
+    st4<NT>(v + i, vv[0], vv[1], vv[2], vv[3]);
+    st4<NT>(target + i, tt[0], tt[1], tt[2], tt[3]);
     theta_b[i] = make_uint2(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]));
     target_b[i] = make_uint2(pack_bf16x2(tt[0], tt[1]), pack_bf16x2(tt[2], tt[3]));
-    if (zero_grads) grads[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zero_grads) st4<NT>(grads + i, 0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -636,10 +664,20 @@ extern "C" int cqlrec_adam_ema(float* theta, float* grads, float* m, float* v, f
   const int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
+  static int nt = -1;
+  if (nt < 0) {
+    const char* e = getenv("CQL_ADAM_NT");
+    nt = (e && *e == '0') ? 0 : 1;
+  }
   CqlProfScope prof(CQLREC_PH_ADAM, (hipStream_t)stream);
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)theta, (float4*)grads,
-                     (float4*)m, (float4*)v, (float4*)target, (uint2*)theta_b, (uint2*)target_b, n4, step_size, sqrt_bc2,
-                     beta1, beta2, eps, tau, zero_grads);
+  if (nt)
+    hipLaunchKernelGGL(adam_ema_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)theta,
+                       (float4*)grads, (float4*)m, (float4*)v, (float4*)target, (uint2*)theta_b, (uint2*)target_b, n4,
+                       step_size, sqrt_bc2, beta1, beta2, eps, tau, zero_grads);
+  else
+    hipLaunchKernelGGL(adam_ema_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)theta,
+                       (float4*)grads, (float4*)m, (float4*)v, (float4*)target, (uint2*)theta_b, (uint2*)target_b, n4,
+                       step_size, sqrt_bc2, beta1, beta2, eps, tau, zero_grads);
   CQL_LAUNCH_CHECK("adam_ema");
   return CQLREC_OK;
 }

@@ -123,6 +123,9 @@ def test_pipelined_steps_match_step_by_step():
     np.testing.assert_allclose(a.theta.cpu().numpy(), b.theta.cpu().numpy(), atol=2e-6)
     np.testing.assert_allclose(a.target.cpu().numpy(), b.target.cpu().numpy(), atol=2e-6)
     assert np.count_nonzero(a.grads.cpu().numpy()) == 0
+    # the two-pass item-side Adam leaves the same shadows as the one-pass kernel
+    assert np.array_equal(bf16_to_np(a.theta_b), O.bf16_round(a.theta.cpu().numpy()))
+    assert np.array_equal(bf16_to_np(a.target_b), O.bf16_round(a.target.cpu().numpy()))
     # views of a given step stay addressable by parity
     v = a.views(steps - 1)
     pos = O.sample_positions(11, steps - 1, 0, B, int(a._csr[0][-1]))
