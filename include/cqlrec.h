@@ -150,6 +150,25 @@ int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, const float
                             float scale, void* ws, int64_t ws_bytes, float* dH, cqlrec_stream stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * a5+a10 fused ("flash" form), used by the training step: ONE pass over the catalogue yields per state the
+ * logsumexp AND sum_j exp(S_j - m) E_out_b[j] relative to a running reference m (kept in `ws`, one slab per
+ * catalogue slice), so the state-side backward needs no second catalogue pass.  Once the TD coefficients are
+ * known, dh_finish combines the slabs:
+ *     dH[b] = scale * sum_k slab_k[b] * exp(m_k[b] - lse[b]) + coef[b] * E_out_b[act[b]]
+ * P is rounded to bf16 relative to the running reference instead of the final lse (same 2^-9 relative error per
+ * probability, different rounding points): dH agrees with cqlrec_qhead_bwd_states to ~1e-3 normwise, lse to 1e-6.
+ * Replaces, together with cqlrec_qhead_bwd_items, loss.backward() through the catalogue-wide Linear + log_softmax
+ * (replay/models/mult_vae.py:101, :274-284; replay/models/base_torch_rec.py:37).
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t cqlrec_qhead_fused_ws_bytes(int64_t rows, int64_t n_items, int32_t d);
+int cqlrec_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
+                            int64_t n_items, int32_t d, void* ws, int64_t ws_bytes, float* out_lse,
+                            float* out_nlse2 /* -lse*log2(e), may be NULL */, cqlrec_stream stream);
+int cqlrec_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse,
+                           const float* coef, const int32_t* act, const uint16_t* E_out_b, float scale, float* dH,
+                           cqlrec_stream stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * a7  Fused Adam + Polyak target + bf16 shadows over the flat buffer (S6).  Replaces optimizer.step()
  * (replay/models/base_torch_rec.py:38; torch.optim.Adam at replay/models/neuromf.py:351-355).
  *   m = b1 m + (1-b1) g;  v = b2 v + ((1-b2) g) g;  theta -= step_size * (m / (sqrt(v)/sqrt_bc2 + eps));

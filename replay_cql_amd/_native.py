@@ -90,6 +90,9 @@ SIGNATURES = {
     "cqlrec_train_step_backward_rest": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),
     "cqlrec_set_concurrency": (i32, [i32]),
+    "cqlrec_qhead_fused_ws_bytes": (i64, [i64, i64, i32]),
+    "cqlrec_qhead_fwd_lse_dh": (i32, [vp, i64, vp, vp, i64, i32, vp, i64, vp, vp, vp]),
+    "cqlrec_qhead_dh_finish": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_float, vp, vp]),
     "cqlrec_train_steps": (i32, [C.POINTER(TrainCtx), u64, i32, vp, vp]),
     "cqlrec_train_views_get": (i32, [C.POINTER(TrainCtx), u64, C.POINTER(TrainViews)]),
     "cqlrec_build_csr_ws_bytes": (i64, [i64]),

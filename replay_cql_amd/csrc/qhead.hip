@@ -90,7 +90,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int D, int SPW, int MODE, int NBUF, int MINW>
 __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
   using C = QCfg<D>;
-  constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE);
+  constexpr bool FUSED = (MODE == QM_LSE_DH);          // forward LSE + softmax-weighted sum, running reference
+  constexpr bool BWD = (MODE == QM_BWD_DH || MODE == QM_BWD_DE || FUSED);   // modes with the second MFMA
   constexpr int FT = D / 32;
   constexpr int PD = NBUF - 1;               // prefetch distance in stages
   constexpr int VPS = C::LPS + 1;            // vmcnt units per stage per wave (tile pieces + scalar strip)
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
 #pragma unroll
     for (int s = 0; s < C::KS; ++s)
       rf[g][s] = *reinterpret_cast<const bf16x8*>(a.res + row * D + 16 * s + 8 * h);
-    rs[g] = BWD ? a.res_scalar[row] : 0.f;
+    rs[g] = (BWD && !FUSED) ? a.res_scalar[row] : 0.f;
   }
   // The prologue's ordinary loads must be retired -- in hipcc's own bookkeeping -- before the loop: left alone, it
   // places their counted waits (vmcnt(7) ... vmcnt(0)) at the first use INSIDE the loop, and since our LDS-DMA pieces
@@ -314,11 +315,39 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         bf16x8 pf[SPW][2];
 #pragma unroll
         for (int g = 0; g < SPW; ++g) {
+          if constexpr (FUSED) {
+            // Running reference m (st_a, natural units; rs = -m*log2e), shared by the two lanes of a state.  It only
+            // ever moves when a tile beats it, and then jumps QS_REF_MARGIN above that tile's maximum, so the rescale
+            // of the accumulators (wave-uniform branch) is rare after the first few tiles.  P = exp(S - m) <= 1.
+            float tmax = acc[g][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[g][i]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            const bool need = tmax > st_a[g];
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+              const float nm = need ? tmax + QS_REF_MARGIN : st_a[g];
+              const float f = (st_a[g] == NEG_INF) ? 0.f : fast_exp2((st_a[g] - nm) * CQL_LOG2E);   // 1 when unchanged
+              st_a[g] = nm;
+              rs[g] = -nm * CQL_LOG2E;
+              st_b[g] *= f;
+#pragma unroll
+              for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[g][ft][i] *= f;
+            }
+          }
           float p[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const float off = (MODE == QM_BWD_DH) ? rs[g] : sv[i];
+            const float off = (MODE == QM_BWD_DE) ? sv[i] : rs[g];
             p[i] = fast_exp2(fmaf(acc[g][i], CQL_LOG2E, off));
+          }
+          if constexpr (FUSED) {
+            float cs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cs += p[i];
+            st_b[g] += cs;
           }
           if constexpr (MODE == QM_BWD_DE) {
             float cs = 0.f;
@@ -344,7 +373,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         // program order: the 4*FT transposed reads, then the exp / convert block (their latency hides under it),
         // then the second MFMA chain back to back
         __builtin_amdgcn_sched_group_barrier(0x100, FT * 4, 1);
-        __builtin_amdgcn_sched_group_barrier(0x402, 40 * SPW, 1);
+        __builtin_amdgcn_sched_group_barrier(0x402, (FUSED ? 80 : 40) * SPW, 1);
         __builtin_amdgcn_sched_group_barrier(0x008, FT * 2 * SPW, 1);
       }
     }
@@ -396,6 +425,13 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         if (ok && h == 0) {
           if (a.out) a.out_cs[row] = a.accumulate ? a.out_cs[row] + sc * cs : sc * cs;
           else a.slab_cs[pidx] = cs;
+        }
+      }
+      if constexpr (FUSED) {   // (reference, sum relative to it): what qhead_finalize_lse_kernel merges
+        const float ls = st_b[g] + __shfl_xor(st_b[g], 32);
+        if (ok && h == 0) {
+          a.part_a[pidx] = st_a[g];
+          a.part_b[pidx] = ls;
         }
       }
     }
@@ -459,8 +495,8 @@ static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
 }
 
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
-  static const int phase_of[6] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
-                                  CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE};
+  static const int phase_of[7] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
+                                  CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE, CQLREC_PH_QHEAD_LSE};
   CqlProfScope prof(phase_of[mode], s);
   switch (mode) {
     case QM_LSE:
@@ -474,6 +510,7 @@ int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
       return qs_launch_mode<QM_TILEMAX, 2>(a, d, rblks, s);
     case QM_BWD_DH: return qs_launch_mode<QM_BWD_DH, QS_SPW_BWD>(a, d, rblks, s);
     case QM_BWD_DE: return qs_launch_mode<QM_BWD_DE, QS_SPW_BWD>(a, d, rblks, s);
+    case QM_LSE_DH: return qs_launch_mode<QM_LSE_DH, QS_SPW_BWD>(a, d, rblks, s);
   }
   return -1;
 }
@@ -606,6 +643,45 @@ __global__ __launch_bounds__(256) void qhead_bwd_reduce_kernel(const float* __re
   }
 }
 
+// dH from the fused forward's slabs:  dst[row][f] = scale * sum_k slab[k][row][f] * exp(m[k][row] - lse[row])
+//                                                  + coef[row] * E_b[act[row]][f]
+template <int D>
+__global__ __launch_bounds__(256) void qhead_dh_finish_kernel(const float* __restrict__ slab,
+                                                              const float* __restrict__ pm, int nsplit, int64_t rows,
+                                                              const float* __restrict__ lse, float scale,
+                                                              const float* __restrict__ coef,
+                                                              const int32_t* __restrict__ act,
+                                                              const uint16_t* __restrict__ E_b,
+                                                              float* __restrict__ dst) {
+  constexpr int V = D / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * V) return;
+  const int64_t row = idx / V;
+  const int c = (int)(idx % V);
+  const float nl2 = -lse[row] * CQL_LOG2E;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nsplit; ++k) {
+    const float mk = pm[(int64_t)k * rows + row];
+    const float w = (mk == NEG_INF) ? 0.f : fast_exp2(fmaf(mk, CQL_LOG2E, nl2));
+    const float4 t = *reinterpret_cast<const float4*>(slab + ((int64_t)k * rows + row) * D + c * 4);
+    s.x = fmaf(w, t.x, s.x);
+    s.y = fmaf(w, t.y, s.y);
+    s.z = fmaf(w, t.z, s.z);
+    s.w = fmaf(w, t.w, s.w);
+  }
+  s.x *= scale;
+  s.y *= scale;
+  s.z *= scale;
+  s.w *= scale;
+  const float cf = coef[row];
+  const uint2 e = *reinterpret_cast<const uint2*>(E_b + (int64_t)act[row] * D + c * 4);
+  s.x = fmaf(cf, __uint_as_float(e.x << 16), s.x);
+  s.y = fmaf(cf, __uint_as_float(e.x & 0xFFFF0000u), s.y);
+  s.z = fmaf(cf, __uint_as_float(e.y << 16), s.z);
+  s.w = fmaf(cf, __uint_as_float(e.y & 0xFFFF0000u), s.w);
+  *reinterpret_cast<float4*>(dst + row * D + c * 4) = s;
+}
+
 // sparse one-hot part of dQ:  g_E_out[act[b]] += coef[b] H_b[b];  g_b_out[act[b]] += coef[b]
 template <int D>
 __global__ __launch_bounds__(256) void qhead_bwd_sparse_kernel(const float* __restrict__ coef,
@@ -722,10 +798,15 @@ extern "C" int cqlrec_qhead_bwd_states(const uint16_t* H_b, const float* nlse2, 
 }
 
 // g_E_out / g_b_out only (owner = items, streamed = states)
+// sparse_first: scatter the one-hot part first and let the streaming kernel accumulate (callers with zeroed gradients);
+// [item_lo, item_hi): item rows handled by this call (the scatter, when requested, always covers every item).
 static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,
                                int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
                                float scale, void* ws, int64_t ws_bytes, float* g_E_out, float* g_b_out,
-                               cqlrec_stream stream, bool sparse_first) {
+                               cqlrec_stream stream, bool sparse_first, bool do_sparse = true, int64_t item_lo = 0,
+                               int64_t item_hi = -1) {
+  if (item_hi < 0) item_hi = n_items;
+  CQL_REQUIRE(item_lo >= 0 && item_lo < item_hi && item_hi <= n_items, "qhead_bwd_items: bad item range");
   CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && g_E_out && g_b_out, "qhead_bwd_items: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_bwd_items: d=%d unsupported", d);
   CQL_REQUIRE(batch > 0 && n_items > 0, "qhead_bwd_items: batch=%lld n_items=%lld", (long long)batch, (long long)n_items);
@@ -739,7 +820,7 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
     if (d == 64) SP_DE(64); else if (d == 128) SP_DE(128); else SP_DE(256);
 #undef SP_DE
   };
-  if (sparse_first) launch_sparse();
+  if (sparse_first && do_sparse) launch_sparse();
   // Large catalogues: one block per 128 items streams every state and writes its rows directly (no cross-block
   // sum).  Small catalogues: the state axis is split too, slabs are summed by the small reduce kernel.  (A third
   // variant -- a whole number of resident "rounds" first, the remainder with split states -- measured no faster:
@@ -782,8 +863,8 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
     }
   };
   const int64_t rblks_all = (n_items + 127) / 128;
-  launch_range(0, n_items, rblks_all >= QS_TARGET_BLOCKS_BWD);
-  if (!sparse_first) launch_sparse();
+  launch_range(item_lo, item_hi - item_lo, rblks_all >= QS_TARGET_BLOCKS_BWD);
+  if (!sparse_first && do_sparse) launch_sparse();
   CQL_LAUNCH_CHECK("qhead_bwd_items");
   return CQLREC_OK;
 }
@@ -796,11 +877,86 @@ extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, c
                               g_b_out, stream, false);
 }
 
+// ---- fused forward (training): lse + slabs of the softmax-weighted item sum; see qhead_internal.h ---------------
+struct FusedWs {
+  QSplit sp;
+  float *slab, *part_a, *part_b;
+  int64_t bytes;
+};
+static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
+  FusedWs f;
+  f.sp = qs_choose_split(n_items, rows, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
+  const int64_t slab_b = align256((int64_t)f.sp.nsplit * rows * d * 4), seg = align256((int64_t)f.sp.nsplit * rows * 4);
+  f.slab = (float*)ws;
+  f.part_a = (float*)((char*)ws + slab_b);
+  f.part_b = (float*)((char*)ws + slab_b + seg);
+  f.bytes = slab_b + 2 * seg;
+  return f;
+}
+
+int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                         int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t s) {
+  CQL_REQUIRE(H_b && E_out_b && b_out && ws && out_lse, "qhead_fwd_lse_dh: NULL pointer");
+  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_fwd_lse_dh: d=%d unsupported", d);
+  CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd_lse_dh: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
+  const FusedWs f = fused_ws(ws, rows, n_items, d);
+  CQL_REQUIRE(ws_bytes >= f.bytes, "qhead_fwd_lse_dh: workspace too small");
+  QArgs a = {};
+  a.res = H_b;
+  a.n_res = rows;
+  a.str = E_out_b;
+  a.n_str = n_items;
+  a.str_scalar = b_out;
+  a.nsplit = f.sp.nsplit;
+  a.split_rows = f.sp.split_rows;
+  a.slab = f.slab;
+  a.part_a = f.part_a;
+  a.part_b = f.part_b;
+  a.tg = 1;
+  qs_launch(QM_LSE_DH, a, d, f.sp.rblks, s);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  hipLaunchKernelGGL(qhead_finalize_lse_kernel, dim3(cql_ceil_div(rows, 256)), dim3(256), 0, s, a.part_a, a.part_b,
+                     a.nsplit, rows, out_lse, out_nlse2);
+  CQL_LAUNCH_CHECK("qhead_fwd_lse_dh");
+  return CQLREC_OK;
+}
+
+int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse, const float* coef,
+                        const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t s) {
+  CQL_REQUIRE(ws && lse && coef && act && E_out_b && dH, "qhead_dh_finish: NULL pointer");
+  const FusedWs f = fused_ws(const_cast<void*>(ws), rows, n_items, d);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  const int64_t n4 = rows * (d / 4);
+  dim3 grid(cql_ceil_div(n4, 256)), block(256);
+#define FIN_DH(DD)                                                                                                   \
+  hipLaunchKernelGGL(qhead_dh_finish_kernel<DD>, grid, block, 0, s, f.slab, f.part_a, f.sp.nsplit, rows, lse, scale, \
+                     coef, act, E_out_b, dH)
+  if (d == 64) FIN_DH(64); else if (d == 128) FIN_DH(128); else FIN_DH(256);
+#undef FIN_DH
+  CQL_LAUNCH_CHECK("qhead_dh_finish");
+  return CQLREC_OK;
+}
+
+extern "C" int64_t cqlrec_qhead_fused_ws_bytes(int64_t rows, int64_t n_items, int32_t d) {
+  return fused_ws(nullptr, rows, n_items, d).bytes + 256;
+}
+extern "C" int cqlrec_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
+                                       int64_t n_items, int32_t d, void* ws, int64_t ws_bytes, float* out_lse,
+                                       float* out_nlse2, cqlrec_stream stream) {
+  return cql_qhead_fwd_lse_dh(H_b, rows, E_out_b, b_out, n_items, d, ws, ws_bytes, out_lse, out_nlse2, (hipStream_t)stream);
+}
+extern "C" int cqlrec_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse,
+                                      const float* coef, const int32_t* act, const uint16_t* E_out_b, float scale,
+                                      float* dH, cqlrec_stream stream) {
+  return cql_qhead_dh_finish(ws, rows, n_items, d, lse, coef, act, E_out_b, scale, dH, (hipStream_t)stream);
+}
+
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
-                            int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream) {
+                            int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,
+                            int64_t item_lo, int64_t item_hi) {
   return qhead_bwd_items_impl(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
-                              g_b_out, (cqlrec_stream)stream, true);
+                              g_b_out, (cqlrec_stream)stream, true, do_sparse != 0, item_lo, item_hi);
 }
 
 extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,

@@ -7,12 +7,14 @@
 #define QM_TILEMAX 3
 #define QM_BWD_DH 4
 #define QM_BWD_DE 5
+#define QM_LSE_DH 6         // forward logsumexp AND the softmax-weighted item sum (the soft part of dH) in one pass
 
 #define QS_TI 64            // host-side unit of streamed rows (split boundaries are multiples of it)
 #define QS_SPW_FWD 2        // 32-row owner groups per wave, forward modes (64 states per wave, 256 per block)
 #define QS_SPW_BWD 1        // backward modes (32 owners per wave, 128 per block)
 #define QS_TARGET_BLOCKS 768      // forward modes: 3 blocks per CU resident
 #define QS_TARGET_BLOCKS_BWD 512  // backward modes: 2 blocks per CU resident (register budget)
+#define QS_REF_MARGIN 5.5f   // fused forward: the running reference jumps this far (nats) above a tile maximum that beat it
 #define QS_NBUF 3             // LDS stage buffers (prefetch distance NBUF-1 stages)
 
 struct QArgs {
@@ -49,6 +51,18 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
 // item-side backward for the step driver: the one-hot scatter goes FIRST (into zeroed g_E_out / g_b_out), the streaming
 // kernel then adds its rows -- nothing small is left behind the long kernel on the step's critical path.
+// Fused forward for training ("flash" form): one pass over the catalogue yields, per state, the logsumexp AND
+// sum_j exp(S_j - m) E_out_b[j] relative to a running reference m (slabs in `ws`), so that the state-side backward
+// needs no second pass over the catalogue -- cql_qhead_dh_finish turns the slabs into dH once lse and the TD
+// coefficients are known:  dH[b] = scale * sum_k slab_k[b] * exp(m_k[b] - lse[b]) + coef[b] * E_out_b[act[b]].
+// ws: cqlrec_qhead_bwd_ws_bytes(rows, n_items, d) + cqlrec_qhead_ws_bytes(rows, n_items, d) bytes.
+int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                         int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t stream);
+int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse, const float* coef,
+                        const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t stream);
+// do_sparse: issue the scatter in this call; [item_lo, item_hi): item rows the streaming kernel handles in this call.
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
-                            int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream);
+                            int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,
+                            int64_t item_lo, int64_t item_hi);
+

@@ -54,7 +54,7 @@ struct StepWs {
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
   void *ws_q, *ws_q2, *ws_qb, *ws_qb2, *ws_enc, *ws_gb;
-  int64_t ws_q_bytes, ws_qb_bytes, ws_enc_bytes, ws_gb_bytes;
+  int64_t ws_q_bytes, ws_qb_bytes, ws_qf_bytes, ws_enc_bytes, ws_gb_bytes;
   int64_t total;
 };
 
@@ -100,7 +100,8 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L, uint64_t
   w.ws_q = c.take<char>(w.ws_q_bytes);     // LSE partials (branch A)
   w.ws_q2 = c.take<char>(w.ws_q_bytes);    // ARGMAX partials (branch B runs concurrently)
   w.ws_qb_bytes = cqlrec_qhead_bwd_ws_bytes(B, N, d);
-  w.ws_qb = c.take<char>(w.ws_qb_bytes);    // state-side backward (dH slabs)
+  w.ws_qf_bytes = w.ws_qb_bytes + w.ws_q_bytes;
+  w.ws_qb = c.take<char>(w.ws_qf_bytes);    // fused forward of branch A: slabs of the soft part of dH + LSE partials
   w.ws_qb2 = c.take<char>(w.ws_qb_bytes);   // item-side backward: its own scratch, the two kernels run concurrently
   w.ws_enc_bytes = cqlrec_encoder_bwd_ws_bytes(B, d);
   w.ws_enc = c.take<char>(w.ws_enc_bytes);
@@ -275,7 +276,8 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, B, d, 0, nullptr, w.hb, stream));
   if (g_mark_phase == 2) mark(MK_PROLOGUE, s);
   if (eout_ready) CQL_HIP_TRY(hipStreamWaitEvent(s, eout_ready, 0), "train_step_forward");
-  CQL_TRY(cqlrec_qhead_fwd(w.hb, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_LSE, w.ws_q, w.ws_q_bytes, w.lse, nullptr, w.nlse2, stream));
+  // logsumexp AND the softmax-weighted sum of item rows (the soft part of dH) in ONE pass over the catalogue
+  CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s));
   if (g_mark_phase == 2) mark(MK_LSE, s);
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
@@ -300,26 +302,20 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   return CQLREC_OK;
 }
 
-// The two halves of the Q-head backward are both MFMA-bound: run together they just share the chip and finish
-// together, and the chain behind the state side (encoder + gather backward, Adam on E_in: HBM / latency bound) would
-// start only then.  So the state-side kernel goes first with the chip to itself (512 blocks = one full round at cfg3)
-// and the item-side kernel, on its own stream, starts when it is done (event `dh`) and runs UNDER that chain.
-int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+// item-side backward over item rows [lo, hi) (hi < 0: all); the one-hot scatter is issued when lo == 0.  ctx->grads is
+// zero on entry (contract of the step): scatter first, the streaming kernel accumulates.
+int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, int64_t lo = 0, int64_t hi = -1) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d;
-  SideStream& ss = side_stream();
-  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.dh, 0), "train_step_backward_items");
   StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
-  // ctx->grads is zero on entry (contract of the step): scatter first, the streaming kernel accumulates
   return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
                                  w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, lo == 0, lo, hi);
 }
 
-// records `dh` behind the dH kernel: the item-side backward waits for it (see above), and so does the item-side Adam
-// (dH is the last reader of the E_out shadow on this stream)
+// records `dh` behind dh_finish, the last reader of the E_out shadow on this stream: the item-side Adam waits for it
 int backward_states_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d;
@@ -327,8 +323,9 @@ int backward_states_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream
   StepWs w = carve_step(c->ws, B, N, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
-  CQL_TRY(cqlrec_qhead_bwd_states(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, N, d, c->alpha * inv_batch, w.ws_qb,
-                                  w.ws_qb_bytes, w.dH, stream));
+  // the catalogue pass was done by the forward: only the slabs are combined here (scale, exp(m - lse), + coef * E[a])
+  CQL_TRY(cql_qhead_dh_finish(w.ws_qb, B, N, d, w.lse, w.coef, w.act, p.Eout_b, c->alpha * inv_batch, w.dH,
+                              (hipStream_t)stream));
   SideStream& ss = side_stream();
   if (ss.ok) CQL_HIP_TRY(hipEventRecord(ss.dh, (hipStream_t)stream), "train_step_backward_rest");
   return CQLREC_OK;
@@ -378,17 +375,18 @@ extern "C" int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* c, uint64
 extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
                                          cqlrec_stream stream) {
   CQL_TRY(cqlrec_train_step_forward(c, step, loss_out, stream));
+  // The item-side backward (one long MFMA-bound kernel) runs on its own stream UNDER the state-side chain (dh_finish,
+  // encoder and window-gather backward: latency / HBM bound).  Fork after the loss, join before returning.
   SideStream& ss = side_stream();
   hipStream_t s = (hipStream_t)stream;
-  CQL_TRY(backward_states_impl(c, step, stream));                        // dH first, records ss.dh behind it
-  if (ss.ok) {
-    CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));          // waits for ss.dh, runs under the chain
+  if (ss.ok && hipEventRecord(ss.loss, s) == hipSuccess && hipStreamWaitEvent(ss.s, ss.loss, 0) == hipSuccess) {
+    CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));
     CQL_HIP_TRY(hipEventRecord(ss.items, ss.s), "train_step_fwd_bwd");
-    CQL_TRY(backward_chain_impl(c, step, stream));
+    CQL_TRY(backward_rest_impl(c, step, stream));
     CQL_HIP_TRY(hipStreamWaitEvent(s, ss.items, 0), "train_step_fwd_bwd");
     return CQLREC_OK;
   }
-  CQL_TRY(backward_chain_impl(c, step, stream));
+  CQL_TRY(backward_rest_impl(c, step, stream));
   return backward_items_impl(c, step, stream);
 }
 
@@ -424,18 +422,20 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
         CQL_HIP_TRY(hipEventRecord(ss.presample, ss.s2), "train_steps");
         sampled = ss.presample;
       }
-      CQL_TRY(backward_states_impl(c, step, stream));                      // dH, records ss.dh
-      if (g_mark_phase == 1) mark(MK_DH, s);
-      CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));          // waits for ss.dh
+      CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.loss, 0), "train_steps");
+      CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));          // sparse scatter, then the long dE_out kernel
       if (g_mark_phase == 1) mark(MK_DE, ss.s);
+      CQL_TRY(backward_states_impl(c, step, stream));                      // dh_finish, records ss.dh
+      if (g_mark_phase == 1) mark(MK_DH, s);
+      CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.dh, 0), "train_steps");     // dh_finish reads the E_out shadow
       CQL_TRY(cqlrec_train_step_update_range(c, step, L.off_E_out, L.off_W1, (cqlrec_stream)ss.s));
+      CQL_HIP_TRY(hipEventRecord(ss.eout, ss.s), "train_steps");
       if (g_mark_phase == 1) mark(MK_ADAM_OUT, ss.s);
       CQL_TRY(backward_chain_impl(c, step, stream));                       // encoder, window gather
       if (g_mark_phase == 1) mark(MK_CHAIN, s);
       CQL_TRY(cqlrec_train_step_update_range(c, step, L.off_W1, L.total, stream));
       CQL_TRY(cqlrec_train_step_update_range(c, step, 0, L.off_E_out, stream));
       if (g_mark_phase == 1) { mark(MK_ADAM_IN, s); g_mark_phase = 2; }
-      CQL_HIP_TRY(hipEventRecord(ss.eout, ss.s), "train_steps");
       pending = ss.eout;
     } else {
       CQL_TRY(backward_rest_impl(c, step, stream));

@@ -346,6 +346,42 @@ def test_qhead_bwd(lib, B, Nn, d):
     assert np.abs(gE.cpu().numpy() - gE_ref).max() < 3e-3 * np.abs(gE_ref).max()
 
 
+@pytest.mark.parametrize("B,Nn,d,ramp", [(32, 64, 64, 0.0), (50, 257, 64, 0.0), (128, 1000, 128, 0.0), (300, 4099, 128, 0.02),
+                                         (96, 513, 256, 0.0), (1024, 10007, 64, 0.0), (64, 20000, 128, 0.01)])
+def test_qhead_fused_forward_dh(lib, B, Nn, d, ramp):
+    """One-pass forward (lse + softmax-weighted item sum relative to a running reference) + dh_finish == the
+    two-pass definition: lse to 1e-5, dH to 3e-3 normwise (P is rounded to bf16 at a different scale).  `ramp` adds a
+    bias growing with the item id, so the running reference keeps being beaten and the rescale path runs often."""
+    Hb, Eb, b = _qhead_inputs(B, Nn, d, False, B + Nn + 1)
+    Hb = O.bf16_round(Hb * 0.5)
+    b = (b + ramp * np.arange(Nn, dtype=np.float32)).astype(np.float32)
+    rng = np.random.default_rng(B + 5)
+    act = rng.integers(0, Nn, B).astype(np.int32)
+    coef = (rng.standard_normal(B) * 0.01).astype(np.float32)
+    scale = np.float32(1.0 / B)
+    Q = O.qvalues(Hb, Eb, b)
+    lse = O.logsumexp_rows(Q)
+    P = np.exp(Q.astype(np.float64) - lse[:, None])
+    dH_ref = scale * (P @ Eb.astype(np.float64)) + coef[:, None] * Eb[act]
+
+    nb = int(lib.cqlrec_qhead_fused_ws_bytes(B, Nn, d))
+    ws = ws_bytes_tensor(nb)
+    lse_d = torch.empty(B, dtype=torch.float32, device=DEV)
+    nl2_d = torch.empty(B, dtype=torch.float32, device=DEV)
+    dH = torch.empty((B, d), dtype=torch.float32, device=DEV)
+    Eb_d = bf16_dev(Eb)
+    N.check(lib.cqlrec_qhead_fwd_lse_dh(ptr(bf16_dev(Hb)), B, ptr(Eb_d), ptr(dev(b)), Nn, d, ptr(ws), nb, ptr(lse_d),
+                                        ptr(nl2_d), stream()))
+    N.check(lib.cqlrec_qhead_dh_finish(ptr(ws), B, Nn, d, ptr(lse_d), ptr(dev(coef)), ptr(dev(act)), ptr(Eb_d),
+                                       float(scale), ptr(dH), stream()))
+    sync()
+    np.testing.assert_allclose(lse_d.cpu().numpy(), lse, rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(nl2_d.cpu().numpy(), -lse_d.cpu().numpy() * np.float32(1.4426950408889634), rtol=1e-6)
+    got = dH.cpu().numpy()
+    assert rel_err(got, dH_ref) < 3e-3
+    assert np.abs(got - dH_ref).max() < 4e-3 * np.abs(dH_ref).max()
+
+
 # ------------------------------------------------------------------------------------------------ Adam
 def test_adam_bit_exact(lib):
     n = 64 * 1000
