@@ -136,11 +136,10 @@ def main():
         N.check(lib.cqlrec_set_concurrency(0), "set_concurrency")
     run(args.warmup, 0)
     barrier()
-    # Inside the timed region only the kernel the `roofline` object reports on (and, on the main stream, Adam) is
-    # bracketed with HIP events: every event pair costs two barrier packets on its stream, and bracketing all ~35
+    # Inside the timed region only the kernel the `roofline` object reports on is bracketed with HIP events: every event pair costs two barrier packets on its stream, and bracketing all ~35
     # launches of a step slows the step by ~14 % (measured).  All phases are bracketed in the serialised pass below.
     if not args.no_prof:
-        dom = (1 << N.PHASES.index("qhead_bwd_de")) | (1 << N.PHASES.index("adam"))
+        dom = 1 << N.PHASES.index("qhead_bwd_de")
         N.check(lib.cqlrec_prof_select(0xFFFFFFFF if args.serial else dom), "prof_select")
         N.check(lib.cqlrec_prof_enable(1), "prof_enable")
     t0 = time.perf_counter()
@@ -239,13 +238,21 @@ def main():
             else "timed region (run with --serial)"
         if phases_timed is not phases:
             out["kernel_ms_per_step_overlapped"] = {p: round(ms / args.steps, 4) for p, (ms, n) in phases_timed.items() if n}
-        qk = {p: phases[p][0] / max(phases[p][1], 1) for p in ("qhead_lse", "qhead_argmax", "qhead_bwd_dh", "qhead_bwd_de")}
+        # Q-head kernels of a step: the fused forward of branch A (phase "qhead_lse": logsumexp AND the softmax-weighted
+        # item sum, i.e. the forward GEMM + the dH GEMM of SURVEY 8(d) in one catalogue pass), the argmax of branch B, the
+        # item-side backward (dE_out).  "qhead_bwd_dh" only appears when the two-pass ABI entry point is used.
+        qk = {p: phases[p][0] / phases[p][1] for p in ("qhead_lse", "qhead_argmax", "qhead_bwd_dh", "qhead_bwd_de")
+              if phases[p][1]}
+        gemms = {"qhead_lse": 2, "qhead_argmax": 1, "qhead_bwd_dh": 1, "qhead_bwd_de": 1}   # algorithmic GEMMs per launch
         dom = max(qk, key=qk.get)
         flops = 2.0 * B * NI * d          # algorithmic flops of ONE Q-head GEMM (8*B*N*d per step = 4 GEMMs)
-        ach = flops / (qk[dom] * 1e-3) / 1e12
+        ach = gemms[dom] * flops / (qk[dom] * 1e-3) / 1e12
         out["roofline"] = {"kernel": f"qstream_kernel<{dom}>", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_ms": qk[dom],
-                           "algorithmic_flops_per_launch": flops}
+                           "algorithmic_flops_per_launch": gemms[dom] * flops}
+        out["roofline_qhead_kernels"] = {
+            p: {"avg_ms": round(ms, 4), "algorithmic_tflops": round(gemms[p] * flops / (ms * 1e-3) / 1e12, 1),
+                "frac": round(gemms[p] * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)} for p, ms in qk.items()}
         if phases_timed is not phases and phases_timed.get(dom, (0, 0))[1]:
             # the same kernel bracketed inside the timed region, where it shares the chip with the state-side backward
             out["roofline"]["avg_ms_timed_region_overlapped"] = phases_timed[dom][0] / phases_timed[dom][1]

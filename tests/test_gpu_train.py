@@ -132,6 +132,36 @@ def test_pipelined_steps_match_step_by_step():
     assert np.array_equal(v["tpos"].cpu().numpy(), O.positions_to_transitions(pos, a._csr[0].cpu().numpy())[1])
 
 
+def test_large_catalogue_direct_output_steps():
+    """Catalogues of >= 65 536 items: the item-side backward kernel runs in its direct-output mode (one block per 128
+    items writes its gradient rows itself, on top of the scattered one-hot part).  Pipelined steps == step by step,
+    and the oracle's trajectory."""
+    from replay_cql_amd import _native as N
+    U, Nn, d, B, L, steps = 200, 66000, 64, 128, 6, 4
+    m, a, (off, items, rew) = _make(U, Nn, d, B, L)
+    _, b, _ = _make(U, Nn, d, B, L)
+    la = torch.zeros(steps, device=DEV)
+    a.train_steps(steps, la)                       # pipelined
+    lb = torch.zeros(steps, device=DEV)
+    N.check(N.load().cqlrec_set_concurrency(0))
+    try:
+        for i in range(steps):                     # strict program order
+            b.forward_backward(lb[i:i + 1])
+            b.apply_update()
+    finally:
+        N.check(N.load().cqlrec_set_concurrency(1))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-5)
+    for name in ("theta", "target", "adam_m", "adam_v"):
+        np.testing.assert_allclose(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), atol=2e-6, err_msg=name)
+    assert np.count_nonzero(a.grads.cpu().numpy()) == 0
+    assert np.array_equal(bf16_to_np(a.theta_b), O.bf16_round(a.theta.cpu().numpy()))
+    assert np.array_equal(bf16_to_np(a.target_b), O.bf16_round(a.target.cpu().numpy()))
+    ref = O.train_steps(m, off, items, rew, steps, B, L, seed=11)
+    np.testing.assert_allclose(la.cpu().numpy(), ref, rtol=1e-3)
+    assert rel_err(a.theta.cpu().numpy(), m.theta) < 1e-3
+
+
 def test_core_predict_matches_oracle():
     U, Nn, d, L, k = 150, 2000, 128, 10, 10
     m, core, (off, items, rew) = _make(U, Nn, d, 128, L)
