@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the streaming Q-head kernels at a BASELINE shape (inputs resident in HBM, HIP-event timing
+"""Micro-benchmark of the streaming Q-head kernels (phase "qhead_lse" counts both the plain LSE launch of mode `lse`
+and the fused LSE+dH launch of mode `fused`: run them in separate invocations to tell them apart) at a BASELINE shape (inputs resident in HBM, HIP-event timing
 through the library's measurement hooks).  Used for A/B-ing kernel variants and as the rocprofv3 --pmc target.
 
     python tools/qhead_microbench.py [--batch 4096] [--items 100000] [--d 128] [--reps 20] [--modes lse,argmax,bwd,topk]
@@ -21,7 +22,7 @@ def main():
     ap.add_argument("--items", type=int, default=100_000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--modes", default="lse,argmax,bwd,topk")
+    ap.add_argument("--modes", default="lse,argmax,fused,bwd,topk")
     ap.add_argument("--topk-users", type=int, default=16384)
     a = ap.parse_args()
     lib = N.load()
@@ -67,7 +68,14 @@ def main():
     def run_topk():
         N.check(lib.cqlrec_score_topk(Hu.data_ptr(), nu, E.data_ptr(), b.data_ptr(), NI, d, None, None, None, None, k,
                                       wsk.data_ptr(), wsk.numel(), oi.data_ptr(), ov.data_ptr(), oc.data_ptr(), s))
-    fns = {"lse": run_lse, "argmax": run_argmax, "bwd": run_bwd, "topk": run_topk}
+    wsf = torch.empty(int(lib.cqlrec_qhead_fused_ws_bytes(B, NI, d)), dtype=torch.uint8, device=dev)
+
+    def run_fused():   # the training step's forward of branch A: logsumexp + softmax-weighted item sum in one pass
+        N.check(lib.cqlrec_qhead_fwd_lse_dh(H.data_ptr(), B, E.data_ptr(), b.data_ptr(), NI, d, wsf.data_ptr(), wsf.numel(),
+                                            lse.data_ptr(), nlse2.data_ptr(), s))
+        N.check(lib.cqlrec_qhead_dh_finish(wsf.data_ptr(), B, NI, d, lse.data_ptr(), coef.data_ptr(), act.data_ptr(),
+                                           E.data_ptr(), 1.0 / B, dH.data_ptr(), s))
+    fns = {"lse": run_lse, "argmax": run_argmax, "fused": run_fused, "bwd": run_bwd, "topk": run_topk}
     run_lse()
     torch.cuda.synchronize()
     for m in modes:
