@@ -250,6 +250,15 @@ def main():
         out["roofline"] = {"kernel": f"qstream_kernel<{dom}>", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_ms": qk[dom],
                            "algorithmic_flops_per_launch": gemms[dom] * flops}
+        # `traffic`: HBM bytes per launch from the PMC counters -- collected in separate rocprofv3 --pmc passes (they cannot
+        # be read from inside this process) and committed with their provenance; only valid for the shape they were taken on
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            if pmc["config"] == {"batch": B, "items": NI, "d": d} and dom in pmc["kernels"]:
+                out["roofline"]["traffic"] = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = pmc["source"] + "; " + pmc["correction"]
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline_qhead_kernels"] = {
             p: {"avg_ms": round(ms, 4), "algorithmic_tflops": round(gemms[p] * flops / (ms * 1e-3) / 1e12, 1),
                 "frac": round(gemms[p] * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)} for p, ms in qk.items()}
