@@ -124,13 +124,10 @@ def main():
     loss_buf = torch.zeros(args.warmup + args.steps + 1, device=dev)
 
     def run(n, base):
-        if world == 1:
-            # one library call per <=64 steps: the step loop is in C++ and pipelined across steps (cqlrec_train_steps)
-            for lo_ in range(0, n, 64):
-                core.train_steps(min(64, n - lo_), loss_buf[base + lo_:])
-            return
-        for i in range(n):
-            core.train_step(loss_buf[base + i: base + i + 1])
+        # <=64 steps per call, pipelined across steps: one library call (single rank: the step loop is in C++,
+        # cqlrec_train_steps) or the phased data-parallel loop around the two asynchronous gradient all-reduces
+        for lo_ in range(0, n, 64):
+            core.train_steps(min(64, n - lo_), loss_buf[base + lo_:])
 
     if args.serial:
         N.check(lib.cqlrec_set_concurrency(0), "set_concurrency")

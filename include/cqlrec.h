@@ -245,6 +245,13 @@ int cqlrec_train_step_update(const cqlrec_train_ctx* ctx /* [host] */, uint64_t 
  *   update_range    Adam/Polyak/shadows/zero-grads over elements [lo, hi) (multiples of 4) */
 int cqlrec_train_step_forward(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,
                               cqlrec_stream stream);
+/* The same with a dependency the caller still has in flight on ANOTHER stream: `items_ready` (a hipEvent_t, or NULL)
+ * completes when the item-side parameters (E_out, b_out, their shadows and target copies) are up to date.  Sampling,
+ * window gathers and both encoders -- they read only E_in / W1 / W2 -- are enqueued in front of the wait, only the
+ * catalogue-wide kernels behind it.  A data-parallel caller uses it to start step t+1 while the all-reduce and Adam of
+ * the item-side half of step t are still running on its side stream. */
+int cqlrec_train_step_forward_after(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,
+                                    cqlrec_stream stream, void* items_ready /* hipEvent_t */);
 int cqlrec_train_step_backward_items(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
 int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
 int cqlrec_train_step_update_range(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, int64_t lo, int64_t hi,

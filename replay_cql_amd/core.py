@@ -172,56 +172,76 @@ class CQLCore:
             allreduce_sum_(self.grads, self.pg)
 
     def train_step(self, loss_out: Optional[torch.Tensor] = None, phased: Optional[bool] = None) -> None:
-        """One full CQL step.  Single GPU: fused fwd_bwd + update.  Data parallel (or phased=True): the step runs in
-        phases so that the all-reduce of the catalogue-side gradients (E_out, b_out: half of the bytes) overlaps the
-        state-side backward, and Adam on that half overlaps the all-reduce of the rest (E_in + encoder)."""
+        """One full CQL step (see train_steps; joined before returning)."""
+        self.train_steps(1, loss_out, phased)
+
+    def train_steps(self, n_steps: int, losses: Optional[torch.Tensor] = None, phased: Optional[bool] = None) -> None:
+        """n_steps whole steps, pipelined across steps, joined on the current stream before returning.
+        losses: optional contiguous float32 device tensor with >= n_steps elements (this rank's share of the loss).
+
+        Single rank: ONE library call, the step loop runs in C++ (cqlrec_train_steps).
+        Data parallel (or phased=True): each step runs in phases around two asynchronous all-reduces --
+          main stream: forward(t) . state-side backward . all-reduce(E_in, encoder grads) . Adam on that half .
+                       [sampling, gathers, encoders of step t+1] . wait . Q-head kernels of step t+1 ...
+          side stream: item-side backward . all-reduce(E_out, b_out grads: half of the bytes) . Adam on that half
+        so the second all-reduce and its Adam run under the first half's Adam and the next step's prologue; only the
+        catalogue-wide kernels of step t+1 wait for them (cqlrec_train_step_forward_after)."""
+        n_steps = int(n_steps)
+        if losses is not None and (losses.numel() < n_steps or losses.dtype != torch.float32 or not losses.is_contiguous()):
+            raise ValueError("losses must be a contiguous float32 tensor with at least n_steps elements")
         phased = (self.world > 1) if phased is None else phased
+        c = self._train_ctx()
         if not phased:
-            if self.world == 1:
-                self.train_steps(1, loss_out)
+            if self.world != 1:
+                for i in range(n_steps):
+                    self.forward_backward(None if losses is None else losses[i:i + 1])
+                    self.allreduce_grads()
+                    self.apply_update()
                 return
-            self.forward_backward(loss_out)
-            self.allreduce_grads()
-            self.apply_update()
+            N.check(self.lib.cqlrec_train_steps(C.byref(c), self.step, n_steps, _ptr(losses), _stream()), "train_steps")
+            self.step += n_steps
             return
-        c, s, lay = self._train_ctx(), _stream(), self.layout
+        s, lay = _stream(), self.layout
         lo_a, hi_a, total = int(lay.off_E_out), int(lay.off_W1), int(lay.total)
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+            self._ev = [torch.cuda.Event() for _ in range(3)]       # forward done, state-side backward done, items ready
         side = self._side
-        N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(loss_out), s), "train_step_forward")
-        side.wait_stream(main)
-        # state-side backward on this stream: its dH kernel goes first; the item-side backward (+ its all-reduce), on
-        # the side stream, waits inside the library for that kernel and then runs under the encoder / gather backward
-        N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
-        with torch.cuda.stream(side):
-            N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
-                    "train_step_backward_items")
-            work_a = self._allreduce_async(self.grads[lo_a:hi_a])
-        work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
-        if work_a is not None:
-            work_a.wait()          # stream-side wait (RCCL): no host block
-        else:
-            main.wait_stream(side)
-        N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, lo_a, hi_a, s), "update_range")
-        for w in work_b:
-            if w is not None:
-                w.wait()
-        N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, 0, lo_a, s), "update_range")
-        N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, hi_a, total, s), "update_range")
-        self.step += 1
-
-    def train_steps(self, n_steps: int, losses: Optional[torch.Tensor] = None) -> None:
-        """n_steps whole steps in ONE library call (single rank): the step loop runs in C++, software-pipelined across
-        steps (cqlrec_train_steps).  losses: optional device float tensor with >= n_steps elements."""
-        if self.world != 1:
-            raise RuntimeError("train_steps is the single-rank path; data-parallel jobs use train_step/train")
-        if losses is not None and (losses.numel() < n_steps or losses.dtype != torch.float32 or not losses.is_contiguous()):
-            raise ValueError("losses must be a contiguous float32 tensor with at least n_steps elements")
-        c = self._train_ctx()
-        N.check(self.lib.cqlrec_train_steps(C.byref(c), self.step, int(n_steps), _ptr(losses), _stream()), "train_steps")
-        self.step += int(n_steps)
+        ev_fwd, ev_rest, ev_items = self._ev
+        pending = False
+        for i in range(n_steps):
+            lo = None if losses is None else losses[i:i + 1]
+            if pending:
+                N.check(self.lib.cqlrec_train_step_forward_after(C.byref(c), self.step, _ptr(lo), s, ev_items.cuda_event),
+                        "train_step_forward_after")
+            else:
+                N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(lo), s), "train_step_forward")
+            ev_fwd.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_fwd)
+                N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
+                        "train_step_backward_items")
+                work_a = self._allreduce_async(self.grads[lo_a:hi_a])
+            N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
+            ev_rest.record(main)
+            work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
+            for w in work_b:
+                if w is not None:
+                    w.wait()           # stream-side wait (RCCL): no host block
+            N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, hi_a, total, s), "update_range")
+            N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, 0, lo_a, s), "update_range")
+            with torch.cuda.stream(side):
+                if work_a is not None:
+                    work_a.wait()
+                side.wait_event(ev_rest)   # the state-side backward reads rows of the E_out shadow (coef * E_out[a])
+                N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, lo_a, hi_a, side.cuda_stream),
+                        "update_range")
+                ev_items.record(side)
+            pending = True
+            self.step += 1
+        if pending:
+            main.wait_event(ev_items)
 
     def _allreduce_async(self, t: torch.Tensor):
         if self.world <= 1:
@@ -233,13 +253,9 @@ class CQLCore:
         """n_steps CQL steps; returns the per-step (rank-local share of the) loss as a device tensor -- no host sync
         inside the loop (cf. loss.item() per step at replay/models/base_torch_rec.py:39)."""
         losses = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=self.device)
-        if self.world == 1 and not phased:
-            # chunks keep the host at most a few thousand launches ahead of the device
-            for lo in range(0, n_steps, 64):
-                self.train_steps(min(64, n_steps - lo), losses[lo:])
-            return losses[:n_steps]
-        for i in range(n_steps):
-            self.train_step(losses[i:i + 1], phased)
+        # chunks keep the host at most a few thousand launches ahead of the device
+        for lo in range(0, n_steps, 64):
+            self.train_steps(min(64, n_steps - lo), losses[lo:], phased)
         if self.world > 1 and n_steps > 0:
             import torch.distributed as dist
             dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=self.pg)

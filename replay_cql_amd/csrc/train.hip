@@ -359,6 +359,12 @@ extern "C" int cqlrec_train_step_forward(const cqlrec_train_ctx* c, uint64_t ste
   return forward_impl(c, step, loss_out, stream, nullptr);
 }
 
+extern "C" int cqlrec_train_step_forward_after(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
+                                               cqlrec_stream stream, void* items_ready) {
+  CQL_TRY(check_ctx(c));
+  return forward_impl(c, step, loss_out, stream, (hipEvent_t)items_ready);
+}
+
 // phase 2: the catalogue-side gradients g_E_out, g_b_out (half of the gradient bytes; a data-parallel caller starts
 // their all-reduce while phase 3 runs)
 extern "C" int cqlrec_train_step_backward_items(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
