@@ -218,14 +218,17 @@ class CQLCore:
             else:
                 N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(lo), s), "train_step_forward")
             ev_fwd.record(main)
+            N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
+            ev_rest.record(main)
+            # issue order matters: the collectives of one process group execute in the order they were issued (one
+            # internal RCCL stream), so the state-side all-reduce -- whose gradients are ready first -- goes first and
+            # runs under the item-side kernel; the item-side all-reduce queues behind it
+            work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
             with torch.cuda.stream(side):
                 side.wait_event(ev_fwd)
                 N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
                         "train_step_backward_items")
                 work_a = self._allreduce_async(self.grads[lo_a:hi_a])
-            N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
-            ev_rest.record(main)
-            work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
             for w in work_b:
                 if w is not None:
                     w.wait()           # stream-side wait (RCCL): no host block
