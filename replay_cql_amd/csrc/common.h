@@ -45,6 +45,13 @@ struct CqlProfScope {
   ~CqlProfScope() { cql_prof_end(s); }
 };
 
+// deterministic one-hot scatter of the Q-head backward (gbwd.hip): sort of (act[b], b) ahead of time, then a segmented sum
+int64_t cql_onehot_ws_bytes(int64_t batch, int32_t d);
+int cql_onehot_prepare(const int32_t* act, int64_t batch, int64_t n_items, int32_t d, void* ws, int64_t ws_bytes,
+                       hipStream_t s);
+int cql_onehot_apply(const float* coef, const uint16_t* H_b, int64_t batch, int64_t n_items, int32_t d, void* ws,
+                     float* g_E_out, float* g_b_out, hipStream_t s);
+
 static inline int cql_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- bf16 <-> f32 ------------------------------------------------------------------------------------------

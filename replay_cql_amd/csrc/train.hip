@@ -53,8 +53,8 @@ struct StepWs {
   float *rew, *done, *q_a, *lse, *nlse2, *q_targ, *y, *coef, *maxv, *loss;
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
-  void *ws_q, *ws_q2, *ws_qb, *ws_qb2, *ws_enc, *ws_gb;
-  int64_t ws_q_bytes, ws_qb_bytes, ws_qf_bytes, ws_enc_bytes, ws_gb_bytes;
+  void *ws_q, *ws_q2, *ws_qb, *ws_qb2, *ws_enc, *ws_gb, *ws_oh;
+  int64_t ws_q_bytes, ws_qb_bytes, ws_qf_bytes, ws_enc_bytes, ws_gb_bytes, ws_oh_bytes;
   int64_t total;
 };
 
@@ -109,6 +109,10 @@ StepWs carve_step(void* ws, int32_t B, int64_t N, int32_t d, int32_t L, uint64_t
   void* gb0 = c.take<char>(w.ws_gb_bytes);   // sorted (item, state) pairs: by parity as well, the sort of step t+1 is
   void* gb1 = c.take<char>(w.ws_gb_bytes);   // issued while the gather backward of step t has not run yet
   w.ws_gb = (step & 1) ? gb1 : gb0;
+  w.ws_oh_bytes = cql_onehot_ws_bytes(B, d);
+  void* oh0 = c.take<char>(w.ws_oh_bytes);   // sorted (action, transition) pairs of the one-hot scatter, by parity too
+  void* oh1 = c.take<char>(w.ws_oh_bytes);
+  w.ws_oh = (step & 1) ? oh1 : oh0;
   w.total = c.off;
   return w;
 }
@@ -229,8 +233,9 @@ int sample_ahead(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream)
   CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
                                     (uint64_t)c->rank * (uint64_t)c->batch, c->batch, w.users, w.tpos, w.act, w.rew,
                                     w.done, stream));
-  return cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, c->batch, c->window, L.d, L.n_items,
-                                        w.ws_gb, w.ws_gb_bytes, stream);
+  CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, c->batch, c->window, L.d, L.n_items,
+                                         w.ws_gb, w.ws_gb_bytes, stream));
+  return cql_onehot_prepare(w.act, c->batch, L.n_items, L.d, w.ws_oh, w.ws_oh_bytes, (hipStream_t)stream);
 }
 
 int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlrec_stream stream, hipEvent_t eout_ready,
@@ -258,10 +263,12 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   } else if (ss.ok) {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            (cqlrec_stream)ss.s));
+    CQL_TRY(cql_onehot_prepare(w.act, B, N, d, w.ws_oh, w.ws_oh_bytes, ss.s));
     CQL_HIP_TRY(hipEventRecord(ss.joined, ss.s), "train_step_forward");
   } else {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            stream));
+    CQL_TRY(cql_onehot_prepare(w.act, B, N, d, w.ws_oh, w.ws_oh_bytes, s));
   }
   // The forward has two independent branches that meet at the TD target:
   //   A (this stream):  s  under theta  -> encoder -> logsumexp over the catalogue, Q(s, a)
@@ -302,17 +309,24 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   return CQLREC_OK;
 }
 
-// item-side backward over item rows [lo, hi) (hi < 0: all); the one-hot scatter is issued when lo == 0.  ctx->grads is
-// zero on entry (contract of the step): scatter first, the streaming kernel accumulates.
-int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, int64_t lo = 0, int64_t hi = -1) {
+// item-side backward.  ctx->grads is zero on entry (contract of the step).
+int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d;
   StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
+  SideStream& ss = side_stream();
+  // the (action, transition) pairs were sorted ahead of time on another stream (same event as the window pairs)
+  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.joined, 0), "train_step_backward_items");
+  // one-hot part first, as a deterministic segmented sum into the zeroed gradient rows; the long kernel accumulates
+  static const bool atomic_scatter = getenv("CQL_ONEHOT_ATOMIC") && getenv("CQL_ONEHOT_ATOMIC")[0] == '1';   // A/B knob
+  if (!atomic_scatter)
+    CQL_TRY(cql_onehot_apply(w.coef, w.hb, B, L.n_items, d, w.ws_oh, c->grads + L.off_E_out, c->grads + L.off_b_out,
+                             (hipStream_t)stream));
   return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
                                  w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
-                                 (hipStream_t)stream, lo == 0, lo, hi);
+                                 (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1);
 }
 
 // records `dh` behind dh_finish, the last reader of the E_out shadow on this stream: the item-side Adam waits for it

@@ -132,6 +132,33 @@ def test_pipelined_steps_match_step_by_step():
     assert np.array_equal(v["tpos"].cpu().numpy(), O.positions_to_transitions(pos, a._csr[0].cpu().numpy())[1])
 
 
+@pytest.mark.parametrize("U,Nn,d,B,L", [(300, 1000, 128, 256, 8), (200, 66000, 64, 128, 6)])
+def test_steps_are_bit_reproducible(U, Nn, d, B, L):
+    """No float atomics anywhere in the step (sorted segmented sums for both scatters, ordered slab reductions), so the
+    same steps give the same bits: run to run, and pipelined (side streams, cross-step overlap) vs strict program
+    order on one stream -- which also makes this the sharpest race detector of the suite."""
+    from replay_cql_amd import _native as N
+    steps = 6
+    cores = [_make(U, Nn, d, B, L)[1] for _ in range(4)]
+    cores[0].train_steps(steps)
+    cores[1].train_steps(2)
+    cores[1].train_steps(steps - 2)
+    cores[2].train_steps(steps, phased=True)             # the data-parallel phase path on one rank
+    N.check(N.load().cqlrec_set_concurrency(0))
+    try:
+        for _ in range(steps):
+            cores[3].forward_backward(None)
+            cores[3].apply_update()
+    finally:
+        N.check(N.load().cqlrec_set_concurrency(1))
+    torch.cuda.synchronize()
+    ref = cores[3]
+    for i, c in enumerate(cores[:3]):
+        for name in ("theta", "target", "adam_m", "adam_v"):
+            assert torch.equal(getattr(c, name), getattr(ref, name)), (i, name)
+        assert torch.equal(c.theta_b, ref.theta_b) and torch.equal(c.target_b, ref.target_b), i
+
+
 def test_large_catalogue_direct_output_steps():
     """Catalogues of >= 65 536 items: the item-side backward kernel runs in its direct-output mode (one block per 128
     items writes its gradient rows itself, on top of the scattered one-hot part).  Pipelined steps == step by step,
