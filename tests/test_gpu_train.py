@@ -118,10 +118,9 @@ def test_pipelined_steps_match_step_by_step():
         N.check(N.load().cqlrec_set_concurrency(1))
     torch.cuda.synchronize()
     assert a.step == b.step == steps
-    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-5)
-    # float atomics (one-hot scatter, run edges of the gather backward) make the last bits order dependent
-    np.testing.assert_allclose(a.theta.cpu().numpy(), b.theta.cpu().numpy(), atol=2e-6)
-    np.testing.assert_allclose(a.target.cpu().numpy(), b.target.cpu().numpy(), atol=2e-6)
+    assert torch.equal(la, lb)
+    # the step is deterministic (no float atomics): bit for bit
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.target, b.target)
     assert np.count_nonzero(a.grads.cpu().numpy()) == 0
     # the two-pass item-side Adam leaves the same shadows as the one-pass kernel
     assert np.array_equal(bf16_to_np(a.theta_b), O.bf16_round(a.theta.cpu().numpy()))
@@ -178,9 +177,9 @@ def test_large_catalogue_direct_output_steps():
     finally:
         N.check(N.load().cqlrec_set_concurrency(1))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-5)
+    assert torch.equal(la, lb)
     for name in ("theta", "target", "adam_m", "adam_v"):
-        np.testing.assert_allclose(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), atol=2e-6, err_msg=name)
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert np.count_nonzero(a.grads.cpu().numpy()) == 0
     assert np.array_equal(bf16_to_np(a.theta_b), O.bf16_round(a.theta.cpu().numpy()))
     assert np.array_equal(bf16_to_np(a.target_b), O.bf16_round(a.target.cpu().numpy()))
@@ -230,7 +229,6 @@ def test_phased_step_equals_fused_step():
     lb = core_b.train(5, phased=True).cpu().numpy()
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     assert core_a.step == core_b.step == 5
-    torch.testing.assert_close(core_a.theta, core_b.theta, rtol=0, atol=2e-6)
-    torch.testing.assert_close(core_a.target, core_b.target, rtol=0, atol=2e-6)
+    assert torch.equal(core_a.theta, core_b.theta) and torch.equal(core_a.target, core_b.target)
     assert torch.count_nonzero(core_b.grads).item() == 0
     assert torch.equal(core_b.theta_b.float(), core_b.theta.to(torch.bfloat16).float())
