@@ -392,12 +392,6 @@ __global__ __launch_bounds__(64) void topk_select_small_kernel(const uint16_t* _
   const int ns = seen_off ? (int)(seen_off[srow + 1] - so) : 0;
   const unsigned long long lt_mask = (1ull << lane) - 1;
 
-  uint32_t key[KPL];
-#pragma unroll
-  for (int sl = 0; sl < KPL; ++sl) {
-    const int g = sl * 64 + lane;
-    key[sl] = (g < ngroups) ? f32_order_key(tm_t[u * gstride + g]) : 0u;   // real keys are > 0
-  }
   const bool seen_in_lds = ns <= TK_SEEN_LDS;
   if (seen_in_lds) {
     for (int i = lane; i < ns; i += 64) seen_lds[i] = seen_items[so + i];
@@ -407,17 +401,24 @@ __global__ __launch_bounds__(64) void topk_select_small_kernel(const uint16_t* _
   for (int s = 0; s < KS; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(H_b + u * D + 16 * s + 8 * h);
   __syncthreads();
 
-  // ---- per-lane best two unprocessed groups (key, slot); key 0 = none ----------------------------------------------
+  // ---- per-lane best three unprocessed groups (key, slot); key 0 = none.  The group maxima themselves stay in
+  // memory (one coalesced sweep of the user's row here; again only when a lane has handed out all three and still owns
+  // more): keeping the <= 64 keys of a lane in registers cost 64 VGPRs and half of the kernel's occupancy.
   const int nvalid = (ngroups > lane) ? (ngroups - lane + 63) / 64 : 0;   // slots of this lane that hold a group
   unsigned long long done = 0;
-  uint32_t b1k = 0, b2k = 0;
-  int b1s = 0, b2s = 0;
+  uint32_t b1k = 0, b2k = 0, b3k = 0;
+  int b1s = 0, b2s = 0, b3s = 0;
+  const float* tm_row = tm_t + u * gstride;
   auto refill = [&]() {
-    b1k = 0; b2k = 0; b1s = 0; b2s = 0;
-#pragma unroll
+    b1k = 0; b2k = 0; b3k = 0; b1s = 0; b2s = 0; b3s = 0;
+#pragma unroll 8
     for (int sl = 0; sl < KPL; ++sl) {
-      const uint32_t kk = ((done >> sl) & 1ull) ? 0u : key[sl];
-      const bool gt1 = kk > b1k, gt2 = kk > b2k;        // ascending slots + strict '>' keep the earliest on ties
+      const int g = sl * 64 + lane;
+      uint32_t kk = 0u;                                   // real keys are > 0
+      if (g < ngroups && !((done >> sl) & 1ull)) kk = f32_order_key(tm_row[g]);
+      const bool gt1 = kk > b1k, gt2 = kk > b2k, gt3 = kk > b3k;   // ascending slots + strict '>' keep the earliest on ties
+      b3k = gt2 ? b2k : (gt3 ? kk : b3k);
+      b3s = gt2 ? b2s : (gt3 ? sl : b3s);
       b2k = gt1 ? b1k : (gt2 ? kk : b2k);
       b2s = gt1 ? b1s : (gt2 ? sl : b2s);
       b1k = gt1 ? kk : b1k;
@@ -527,9 +528,9 @@ __global__ __launch_bounds__(64) void topk_select_small_kernel(const uint16_t* _
     }
     if (c1 == cw) {                                      // owner lane: pop
       done |= 1ull << b1s;
-      b1k = b2k; b1s = b2s; b2k = 0;
+      b1k = b2k; b1s = b2s; b2k = b3k; b2s = b3s; b3k = 0;
     }
-    // a lane that has handed out both of its bests may still hold the next one: refill (all lanes, rare)
+    // a lane that has handed out all three of its bests may still hold the next one: refill (all lanes, rare)
     const bool empty_but_more = (b1k == 0) && (__popcll(done) < nvalid);
     if (__any(empty_but_more)) refill();
     const int before = ncand;
