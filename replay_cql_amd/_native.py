@@ -5,10 +5,13 @@ never routes through oracle/ or any CPU implementation."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
-_LIB_PATH = Path(__file__).resolve().parent / "libcqlrec.so"
+# CQLREC_LIB: another build of the same library (A/B-ing kernel variants with tools/); default: the in-tree build
+_LIB_PATH = Path(os.environ["CQLREC_LIB"]).resolve() if os.environ.get("CQLREC_LIB") else \
+    Path(__file__).resolve().parent / "libcqlrec.so"
 _lib: Optional[C.CDLL] = None
 
 ABI_VERSION = 1

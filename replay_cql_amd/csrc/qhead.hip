@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
   // ---- LDS-DMA staging: piece (wave, i) fills LDS bytes [(i*4 + wave) KiB, +1 KiB) of the stage buffer -------
   const int dma_row = lane / C::CPR, dma_chp = lane % C::CPR;   // row within the piece, LDS chunk slot
   const uint32_t smem_base = lds_addr(smem);
-  auto issue = [&](int stage) {
-    const uint32_t bufp = __builtin_amdgcn_readfirstlane(smem_base + (stage % NBUF) * C::BUF_BYTES);
+  auto issue = [&](int stage, int buf) {
+    const uint32_t bufp = __builtin_amdgcn_readfirstlane(smem_base + buf * C::BUF_BYTES);
     const int64_t t0 = s_begin + (int64_t)stage * C::TI;
 #pragma unroll
     for (int i = 0; i < C::LPS; ++i) {
@@ -179,18 +179,24 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
 
 #pragma unroll
   for (int s0 = 0; s0 < PD; ++s0)
-    if (s0 < nstage) issue(s0);
+    if (s0 < nstage) issue(s0, s0);
 
-  for (int stage = 0; stage < nstage; ++stage) {
+  // the ring position is a compile-time constant inside the body (NBUF stages per trip of the outer loop), so that
+  // every LDS address of a tile is "per-lane constant + immediate offset": no address arithmetic per read
+  for (int stage0 = 0; stage0 < nstage; stage0 += NBUF) {
+#pragma unroll
+   for (int sb = 0; sb < NBUF; ++sb) {
+    const int stage = stage0 + sb;
+    if (stage >= nstage) break;
     // stage `stage` has landed once at most the younger in-flight stages' pieces are outstanding
     const int younger = (nstage - 1 - stage < PD - 1) ? (nstage - 1 - stage) : (PD - 1);
     if (PD >= 3 && younger == 2) wait_vmcnt<2 * VPS>();
     else if (PD >= 2 && younger == 1) wait_vmcnt<VPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's pieces of this stage landed; everyone left stage-1's buffer
-    if (stage + PD < nstage) issue(stage + PD);
+    if (stage + PD < nstage) issue(stage + PD, (sb + PD) % NBUF);
 
-    const lds_u8* tile = (const lds_u8*)smem + (stage % NBUF) * C::BUF_BYTES;
+    const lds_u8* tile = (const lds_u8*)smem + sb * C::BUF_BYTES;
     const lds_f4* sc = (const lds_f4*)(tile + C::STAGE_BYTES + wave * 256);
 
 #pragma unroll
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, FT * 2 * SPW, 1);
       }
     }
+   }
   }
 
   // ---- write partials -------------------------------------------------------------------------------------
