@@ -36,6 +36,13 @@ struct QCfg {
 };
 
 #define NEG_INF (-__builtin_inff())
+// VALU instructions the scheduler is asked to place between the transposed reads and the second MFMA chain
+#ifndef QS_FUSED_VALU
+#define QS_FUSED_VALU 64
+#endif
+#ifndef QS_BWD_VALU
+#define QS_BWD_VALU 32
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         // program order: the 4*FT transposed reads, then the exp / convert block (their latency hides under it),
         // then the second MFMA chain back to back
         __builtin_amdgcn_sched_group_barrier(0x100, FT * 4, 1);
-        __builtin_amdgcn_sched_group_barrier(0x402, (FUSED ? 80 : 40) * SPW, 1);
+        __builtin_amdgcn_sched_group_barrier(0x402, (FUSED ? QS_FUSED_VALU : QS_BWD_VALU) * SPW, 1);
         __builtin_amdgcn_sched_group_barrier(0x008, FT * 2 * SPW, 1);
       }
     }
@@ -485,7 +492,10 @@ static void qs_launch_n(const QArgs& a, int64_t rblks, hipStream_t s) {
 
 template <int D, int SPW, int MODE>
 static void qs_launch_d(const QArgs& a, int64_t rblks, hipStream_t s) {
-  qs_launch_n<D, SPW, MODE, QS_NBUF, (D == 256 ? 1 : 2)>(a, rblks, s);
+  // ring depth: 3 stages for the single-MFMA forward modes, 2 for the two-MFMA modes (measured: -3..-6 % there, +9 %
+  // on ARGMAX with 2)
+  constexpr int NB = (MODE == QM_BWD_DH || MODE == QM_BWD_DE || MODE == QM_LSE_DH) ? QS_NBUF_BWD : QS_NBUF;
+  qs_launch_n<D, SPW, MODE, NB, (D == 256 ? 1 : 2)>(a, rblks, s);
 }
 
 template <int MODE, int SPW>

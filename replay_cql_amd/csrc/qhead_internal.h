@@ -15,7 +15,12 @@
 #define QS_TARGET_BLOCKS 768      // forward modes: 3 blocks per CU resident
 #define QS_TARGET_BLOCKS_BWD 512  // backward modes: 2 blocks per CU resident (register budget)
 #define QS_REF_MARGIN 5.5f   // fused forward: the running reference jumps this far (nats) above a tile maximum that beat it
-#define QS_NBUF 3             // LDS stage buffers (prefetch distance NBUF-1 stages)
+#ifndef QS_NBUF
+#define QS_NBUF 3             // LDS stage buffers (prefetch distance NBUF-1 stages), forward modes
+#endif
+#ifndef QS_NBUF_BWD
+#define QS_NBUF_BWD 2         // ... two-MFMA modes (BWD_DH, BWD_DE, LSE_DH)
+#endif
 
 struct QArgs {
   const uint16_t* res;       // owner rows   [n_res x D] bf16
