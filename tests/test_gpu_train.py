@@ -220,9 +220,27 @@ def test_core_predict_matches_oracle():
     np.testing.assert_allclose(ps, Q[np.arange(U), pi], atol=2e-3)
 
 
+def test_full_ranking_beyond_the_fused_k_limit():
+    """k > 2048 (full-ranking requests, e.g. metrics over the whole catalogue): per-part complete rankings merged per
+    user.  Dyadic parameters -> scores are exact, so ids AND order must equal the oracle's (score desc, id asc)."""
+    U, Nn, d, L, k = 12, 5000, 64, 6, 3000
+    m, core, (off, items, rew) = _make(U, Nn, d, 64, L, dyadic=True)
+    users = np.arange(U, dtype=np.int32)
+    d_off, d_items = core._csr[0], core._csr[1]
+    hb = core.encode(d_off, d_items, torch.as_tensor(users).to(DEV))
+    seen = items.copy()
+    for u in range(U):
+        seen[off[u]: off[u + 1]] = np.sort(seen[off[u]: off[u + 1]])
+    idx, val, cnt = core.score_topk(hb, k, seen=(d_off, torch.as_tensor(seen).to(DEV)))
+    ridx, rval, rcnt, _ = O.predict_topk(m.layout, m.theta, off, items, users, k, L, filter_seen=True)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(val.cpu().numpy(), rval)
+
+
 def test_phased_step_equals_fused_step():
     """the data-parallel phase split (forward / backward_items / backward_rest / update_range x3, side-stream sort)
-    computes the same step as the fused driver (up to float-atomic order in the gather backward)."""
+    computes the same step as the fused driver."""
     m, core_a, (off, items, rew) = _make(300, 1000, 128, 256, 8)
     _, core_b, _ = _make(300, 1000, 128, 256, 8)
     la = core_a.train(5, phased=False).cpu().numpy()
