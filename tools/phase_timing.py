@@ -72,6 +72,11 @@ def main():
     t64s = sorted(timed(lambda: core.train_steps(64)) / 64 for _ in range(5))
     a.reps = keep
     print(f"core.train_steps(64): min {t64s[0]:.4f}  median {t64s[2]:.4f} ms/step (5 x 512 steps)", flush=True)
+    a.reps, keep = 8, a.reps
+    tph = sorted(timed(lambda: core.train_steps(64, phased=True)) / 64 for _ in range(3))
+    a.reps = keep
+    print(f"core.train_steps(64, phased=True) [the data-parallel step loop, one rank, no collective]: "
+          f"min {tph[0]:.4f} ms/step", flush=True)
     N.check(lib.cqlrec_debug_marks_enable(1))
     core.train_steps(64)
     torch.cuda.synchronize()
