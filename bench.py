@@ -112,7 +112,10 @@ def main():
     U, NI, d, L, B, K = cfg["users"], cfg["items"], cfg["d"], cfg["window"], cfg["batch"], cfg["k"]
     lo, hi = rank * U // world, (rank + 1) * U // world
     off, items, rew = synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi)
-    core = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg)
+    # CQL_SHARD_OPTIMIZER=1: the row-sharded optimizer variant of the data-parallel step (opt-in, ranks > 1)
+    shard_opt = os.environ.get("CQL_SHARD_OPTIMIZER", "0") == "1"
+    core = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg,
+                   shard_optimizer=shard_opt)
     core.set_log(off, items, rew)
 
     def barrier():
@@ -224,7 +227,8 @@ def main():
         "config": {"workload": f"BASELINE.json configs[2]: synthetic {U} users x {NI} items, CQL d={d}, L={L}, "
                                f"B={B}/GPU, bf16 MFMA + fp32 accumulate" if args.config == "cfg3" else args.config,
                    "users": U, "items": NI, "d": d, "window": L, "batch_per_gpu": B, "global_batch": B * world,
-                   "parallelism": f"dp{world} (users sharded by rank, RCCL gradient all-reduce)", "k": K},
+                   "parallelism": f"dp{world} (users sharded by rank, RCCL gradient " +
+                                  ("reduce-scatter, row-sharded Adam, bf16 all-gather)" if core.shard_optimizer else "all-reduce)"), "k": K},
         "transitions_per_sec": world * args.steps * B / dt,
         "loss_first_last": [losses[0], losses[-1]] if losses else None,
     }

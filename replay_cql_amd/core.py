@@ -47,7 +47,8 @@ class CQLCore:
     """Device-resident CQL model + trainer + scorer for one GPU (one process per GPU under data parallelism)."""
 
     def __init__(self, n_items: int, hyper: Optional[CQLHyper] = None, device: Optional[torch.device] = None,
-                 rank: int = 0, world: int = 1, process_group=None, init_seed: int = 7):
+                 rank: int = 0, world: int = 1, process_group=None, init_seed: int = 7,
+                 shard_optimizer: bool = False):
         self.lib = N.load()
         if not torch.cuda.is_available():
             raise N.CqlrecError("CQLCore needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -70,6 +71,12 @@ class CQLCore:
         self._ws: Optional[torch.Tensor] = None
         self._ctx: Optional[N.TrainCtx] = None
         self._side: Optional[torch.cuda.Stream] = None
+        # Row-sharded optimizer (the cfg5 variant): rank r keeps the fp32 masters, Adam moments and target
+        # of rows [r*R, (r+1)*R) of E_in and E_out up to date (R = N // W; the few remaining rows, b_out and the encoder
+        # stay replicated), gradients are reduce-scattered, the bf16 shadows all-gathered.  Same bytes on the links as
+        # the all-reduce, 1/W of the Adam traffic per GPU.  Opt-in; needs world > 1 and N >= W.
+        self.shard_optimizer = bool(shard_optimizer) and self.world > 1 and self.n_items >= self.world
+        self._gshard: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self.init_params(init_seed)
 
     # ------------------------------------------------------------------ parameters
@@ -112,6 +119,8 @@ class CQLCore:
         N.check(self.lib.cqlrec_cast_bf16(_ptr(self.target), _ptr(self.target_b), P, _stream()), "cast_bf16")
 
     def state_dict(self) -> Dict[str, object]:
+        """Full fp32 state.  With the row-sharded optimizer this is a collective: every rank must call it."""
+        self.sync_full_state()
         return {"theta": self.theta.cpu(), "target": self.target.cpu(), "adam_m": self.adam_m.cpu(),
                 "adam_v": self.adam_v.cpu(), "step": self.step, "n_items": self.n_items,
                 "hyper": asdict(self.hyper)}
@@ -191,6 +200,9 @@ class CQLCore:
             raise ValueError("losses must be a contiguous float32 tensor with at least n_steps elements")
         phased = (self.world > 1) if phased is None else phased
         c = self._train_ctx()
+        if self.shard_optimizer:
+            self._train_steps_sharded(n_steps, losses)
+            return
         if not phased:
             if self.world != 1:
                 for i in range(n_steps):
@@ -245,6 +257,115 @@ class CQLCore:
             self.step += 1
         if pending:
             main.wait_event(ev_items)
+
+    # ------------------------------------------------------------------ row-sharded optimizer (opt-in)
+    def _shard_plan(self):
+        lay, d, W, r = self.layout, self.hyper.d, self.world, self.rank
+        R = self.n_items // W
+        n = R * d
+        o_in, o_out, o_w1, total = int(lay.off_E_in), int(lay.off_E_out), int(lay.off_W1), int(lay.total)
+        return {"n": n,
+                "in_region": (o_in, o_in + W * n), "in_own": (o_in + r * n, o_in + (r + 1) * n),
+                "out_region": (o_out, o_out + W * n), "out_own": (o_out + r * n, o_out + (r + 1) * n),
+                # replicated remainder: last N - W*R rows (+ PAD row and alignment padding), b_out, encoder
+                "tail_in": (o_in + W * n, o_out), "tail_out": (o_out + W * n, o_w1), "tail_enc": (o_w1, total)}
+
+    def _adam_shard(self, lo: int, hi: int, g: torch.Tensor, stream: int) -> None:
+        """Adam + Polyak + shadows on elements [lo, hi) of the flat buffers with the gradient taken from `g` (the
+        reduce-scattered shard); scalars exactly as cqlrec_train_step_update_range computes them."""
+        c = self._train_ctx()
+        t = float(self.step + 1)
+        bc1 = 1.0 - float(c.beta1) ** t
+        bc2 = 1.0 - float(c.beta2) ** t
+        step_size = float(np.float32(float(c.lr) / bc1))
+        sqrt_bc2 = float(np.float32(math.sqrt(bc2)))
+
+        def at(tns):
+            return tns.data_ptr() + tns.element_size() * lo
+        N.check(self.lib.cqlrec_adam_ema(at(self.theta), g.data_ptr(), at(self.adam_m), at(self.adam_v), at(self.target),
+                                         at(self.theta_b), at(self.target_b), hi - lo, step_size, sqrt_bc2, c.beta1, c.beta2,
+                                         c.eps, c.tau, 0, stream), "adam_ema (shard)")
+
+    def _train_steps_sharded(self, n_steps: int, losses: Optional[torch.Tensor]) -> None:
+        from .dist import all_gather_into, reduce_scatter_sum
+        import torch.distributed as dist
+        c, s, P = self._train_ctx(), _stream(), self._shard_plan()
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ev = [torch.cuda.Event() for _ in range(3)]
+        if self._gshard is None:
+            self._gshard = (torch.empty(P["n"], dtype=torch.float32, device=self.device),
+                            torch.empty(P["n"], dtype=torch.float32, device=self.device))
+        g_in, g_out = self._gshard
+        side = self._side
+        ev_fwd, ev_rest, ev_items = self._ev
+        pg = self.pg
+
+        def ar(lo, hi):
+            return dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=pg, async_op=True) if hi > lo else None
+
+        def wait(w):
+            if w is not None:
+                w.wait()
+
+        def upd(lo, hi, stream):
+            if hi > lo:
+                N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, lo, hi, stream), "update_range")
+
+        pending = False
+        for i in range(n_steps):
+            lo_ = None if losses is None else losses[i:i + 1]
+            if pending:
+                N.check(self.lib.cqlrec_train_step_forward_after(C.byref(c), self.step, _ptr(lo_), s, ev_items.cuda_event),
+                        "train_step_forward_after")
+            else:
+                N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(lo_), s), "train_step_forward")
+            ev_fwd.record(main)
+            N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
+            ev_rest.record(main)
+            # state side first (its gradients are ready first; collectives of one group run in issue order)
+            w_in = reduce_scatter_sum(g_in, self.grads[P["in_region"][0]: P["in_region"][1]], pg, async_op=True)
+            w_t1, w_t2 = ar(*P["tail_in"]), ar(*P["tail_enc"])
+            with torch.cuda.stream(side):
+                side.wait_event(ev_fwd)
+                N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
+                        "train_step_backward_items")
+                w_out = reduce_scatter_sum(g_out, self.grads[P["out_region"][0]: P["out_region"][1]], pg, async_op=True)
+                w_t3 = ar(*P["tail_out"])
+            wait(w_in), wait(w_t1), wait(w_t2)
+            self._adam_shard(P["in_own"][0], P["in_own"][1], g_in, s)
+            upd(P["tail_in"][0], P["tail_in"][1], s)
+            upd(P["tail_enc"][0], P["tail_enc"][1], s)
+            self.grads[P["in_region"][0]: P["in_region"][1]].zero_()
+            for buf in (self.theta_b, self.target_b):
+                wait(all_gather_into(buf[P["in_region"][0]: P["in_region"][1]],
+                                     buf[P["in_own"][0]: P["in_own"][1]].clone(), pg, async_op=True))
+            with torch.cuda.stream(side):
+                wait(w_out), wait(w_t3)
+                side.wait_event(ev_rest)   # the state-side backward reads rows of the E_out shadow
+                self._adam_shard(P["out_own"][0], P["out_own"][1], g_out, side.cuda_stream)
+                upd(P["tail_out"][0], P["tail_out"][1], side.cuda_stream)
+                self.grads[P["out_region"][0]: P["out_region"][1]].zero_()
+                for buf in (self.theta_b, self.target_b):
+                    wait(all_gather_into(buf[P["out_region"][0]: P["out_region"][1]],
+                                         buf[P["out_own"][0]: P["out_own"][1]].clone(), pg, async_op=True))
+                ev_items.record(side)
+            pending = True
+            self.step += 1
+        if pending:
+            main.wait_event(ev_items)
+
+    def sync_full_state(self) -> None:
+        """Row-sharded optimizer: bring the fp32 masters, Adam moments and target of every rank's rows to all ranks
+        (checkpointing / inspection).  No-op otherwise."""
+        if not self.shard_optimizer:
+            return
+        from .dist import all_gather_into
+        P = self._shard_plan()
+        for buf in (self.theta, self.adam_m, self.adam_v, self.target):
+            for reg, own in (("in_region", "in_own"), ("out_region", "out_own")):
+                all_gather_into(buf[P[reg][0]: P[reg][1]], buf[P[own][0]: P[own][1]].clone(), self.pg)
 
     def _allreduce_async(self, t: torch.Tensor):
         if self.world <= 1:

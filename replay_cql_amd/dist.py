@@ -57,3 +57,29 @@ def max_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def reduce_scatter_sum(out: torch.Tensor, region: torch.Tensor, group=None, async_op: bool = False):
+    """out = this rank's 1/W slice of the SUM over ranks of `region` (numel = W * out.numel()).  RCCL: one
+    reduce-scatter.  gloo has none: all-reduce the region and keep the own slice (same sums; used by the tests that run
+    several ranks on the CPU backend)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return dist.reduce_scatter_tensor(out, region, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    dist.all_reduce(region, op=dist.ReduceOp.SUM, group=group)
+    r, n = dist.get_rank(group), out.numel()
+    out.copy_(region[r * n: (r + 1) * n])
+    return None
+
+
+def all_gather_into(full: torch.Tensor, mine: torch.Tensor, group=None, async_op: bool = False):
+    """full[r*n:(r+1)*n] = rank r's `mine` for every r (n = mine.numel())."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return dist.all_gather_into_tensor(full, mine, group=group, async_op=async_op)
+    w, n = dist.get_world_size(group), mine.numel()
+    parts = [torch.empty_like(mine) for _ in range(w)]
+    dist.all_gather(parts, mine, group=group)
+    for r in range(w):
+        full[r * n: (r + 1) * n].copy_(parts[r])
+    return None

@@ -89,3 +89,36 @@ def test_two_rank_data_parallel_equals_summed_gradients():
                                   grad_scale_batch=B * world).grads
         O.adam_ema_step(m.theta, g, m.m, m.v, m.target, step + 1, 1e-3)
     np.testing.assert_allclose(res[0][1], m.theta, rtol=1e-5, atol=1e-7)
+
+
+def _rs_ag_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    r, w, pg = PD.init_from_env("gloo")
+    n = 96
+    region = torch.arange(world * n, dtype=torch.float32) * (rank + 1)       # rank r contributes (r+1) * [0, 1, 2, ...]
+    mine = torch.empty(n)
+    PD.reduce_scatter_sum(mine, region, pg)
+    full = torch.zeros(world * n)
+    PD.all_gather_into(full, mine * 2, pg)
+    q.put((rank, mine.numpy().copy(), full.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_and_all_gather_helpers_two_ranks():
+    """the exchange steps of the row-sharded optimizer (gloo has no reduce-scatter: the helper falls back to all-reduce +
+    own slice, the same sums)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rs_ag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 96
+    total = np.arange(world * n, dtype=np.float32) * sum(r + 1 for r in range(world))
+    for rank, mine, full in res:
+        assert np.array_equal(mine, total[rank * n: (rank + 1) * n])
+        assert np.array_equal(full, 2 * total)

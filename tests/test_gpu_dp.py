@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 U, NI, D_, L, B, STEPS = 200, 1000, 128, 8, 128, 4
 
 
-def _data():
-    u, i, t, r = O.synth_log(U, NI, seed=8, mean_len=14, max_len=40)
+def _data(n_items=NI):
+    u, i, t, r = O.synth_log(U, n_items, seed=8, mean_len=14, max_len=40)
     return O.build_csr(u, i, t, r, U)
 
 
@@ -26,21 +26,25 @@ def _shard(off, items, rew, lo, hi):
     return off[lo: hi + 1] - off[lo], items[a:b], rew[a:b]
 
 
-def _worker(rank, world, port, theta0, q):
+def _worker(rank, world, port, theta0, q, shard=False, n_items=NI):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     from replay_cql_amd import dist as PD
     from replay_cql_amd.core import CQLCore, CQLHyper
     r, w, pg = PD.init_from_env("gloo")
     torch.cuda.set_device(0)
-    off, items, rew = _data()
+    off, items, rew = _data(n_items)
     lo, hi = PD.shard_range(U, rank, world)
     so, si, sr = _shard(off, items, rew, lo, hi)
-    core = CQLCore(NI, CQLHyper(d=D_, window=L, batch=B, seed=5), device="cuda:0", rank=rank, world=world, process_group=pg)
+    core = CQLCore(n_items, CQLHyper(d=D_, window=L, batch=B, seed=5), device="cuda:0", rank=rank, world=world,
+                   process_group=pg, shard_optimizer=shard)
     core.load_flat(theta0)
     core.set_log(so, si, sr)
     losses = core.train(STEPS)            # world > 1 -> phased step with async all-reduce
-    q.put((rank, core.theta.cpu().numpy(), losses.cpu().numpy()))
+    shadow = core.theta_b.view(torch.int16).cpu().numpy().copy()
+    core.sync_full_state()                # no-op unless the optimizer is row-sharded
+    q.put((rank, core.theta.cpu().numpy(), losses.cpu().numpy(), shadow, core.adam_v.cpu().numpy(),
+           core.target.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,19 +55,44 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_ranks_one_gpu_match_oracle():
-    world, port = 2, _free_port()
-    m = O.OracleModel.create(NI, D_, seed=7)
-    theta0 = m.theta.copy()
+def _run(world, theta0, shard=False, n_items=NI):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, theta0, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, theta0, q, shard, n_items)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("n_items", [NI, NI + 1])          # N divisible by the world size / one replicated remainder row
+def test_row_sharded_optimizer_equals_replicated(n_items):
+    """SURVEY 8(e), cfg5 variant: reduce-scatter of the gradients, Adam on this rank's rows of E_in / E_out only,
+    all-gather of the bf16 shadows.  Same sums, same Adam arithmetic -> after gathering the shards the masters, moments
+    and targets equal the replicated data-parallel run bit for bit, and the shadows every rank computes with are
+    identical on all ranks."""
+    u, i, t, r = O.synth_log(U, n_items, seed=8, mean_len=14, max_len=40)
+    m = O.OracleModel.create(n_items, D_, seed=7)
+    theta0 = m.theta.copy()
+    # the workers rebuild the log from the module constants: patch the item count through the argument only
+    rep = _run(2, theta0, shard=False, n_items=n_items)
+    shd = _run(2, theta0, shard=True, n_items=n_items)
+    assert np.array_equal(shd[0][3], shd[1][3])                  # bf16 shadows identical on both ranks
+    assert np.array_equal(shd[0][3], rep[0][3])                  # ... and equal to the replicated run's
+    for k in (1, 4, 5):                                          # theta, adam_v, target after sync_full_state()
+        assert np.array_equal(shd[0][k], shd[1][k]) and np.array_equal(shd[0][k], rep[0][k]), k
+    assert np.array_equal(shd[0][2], rep[0][2])                  # same losses
+
+
+def test_two_ranks_one_gpu_match_oracle():
+    world = 2
+    m = O.OracleModel.create(NI, D_, seed=7)
+    theta0 = m.theta.copy()
+    res = _run(world, theta0)
     assert np.array_equal(res[0][1], res[1][1])            # replicas bit-identical after identical Adam
     assert np.allclose(res[0][2], res[1][2])               # the reduced loss is the same on both ranks
     off, items, rew = _data()
