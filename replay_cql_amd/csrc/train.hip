@@ -156,7 +156,9 @@ namespace {
 struct SideStream {
   hipStream_t s = nullptr;    // sort of the gather backward (forward phase), item-side backward (backward phase)
   hipStream_t s2 = nullptr;   // branch B of the forward (s' rows: argmax + target network)
-  hipEvent_t forked = nullptr, joined = nullptr, fork2 = nullptr, join2 = nullptr;
+  hipStream_t s3 = nullptr;   // sampling + sorts of the NEXT step (cqlrec_train_steps)
+  hipEvent_t sorted[2] = {nullptr, nullptr};   // sorted pairs of the step with this parity are in place
+  hipEvent_t forked = nullptr, fork2 = nullptr, join2 = nullptr;
   hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr;
   bool ok = false;
   bool tried = false;
@@ -174,18 +176,15 @@ SideStream& side_stream() {
   if (!concurrency_on()) return off;
   if (!ss.tried) {
     ss.tried = true;
-    // Queue priorities steer what the dispatcher does when two long kernels compete: the item-side backward (stream s)
-    // yields to the caller's stream, so that the state-side kernel finishes first and the chain behind it (encoder and
-    // gather backward, Adam on E_in) runs under the rest of the item-side kernel; the branch stream s2 carries small
-    // latency-critical launches and goes first.  CQL_STREAM_PRIO=0 creates plain streams.
-    int least = 0, greatest = 0;
-    const char* pv = getenv("CQL_STREAM_PRIO");
-    if (!(pv && *pv == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-    if (pv && *pv == '0') least = greatest = 0;
-    ss.ok = hipStreamCreateWithPriority(&ss.s, hipStreamNonBlocking, least) == hipSuccess &&
-            hipStreamCreateWithPriority(&ss.s2, hipStreamNonBlocking, greatest) == hipSuccess &&
+    // Plain streams, all of one priority class: mixing priority classes (tried: item-side backward low, branch stream
+    // high) did not steer the dispatcher, and with a fifth stream in the process (the caller's side stream in the
+    // data-parallel step) it serialised unrelated streams -- the phased step went from 0.28 to 0.64 ms at cfg2.
+    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.sorted[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.sorted[1], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.forked, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.joined, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.fork2, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.loss, hipEventDisableTiming) == hipSuccess &&
@@ -226,13 +225,15 @@ namespace {
 // sample + forward + loss (+ the sort for the gather backward, forked onto the side stream).  `eout_ready`: event
 // after which the item-side parameters (E_out, b_out and their shadows) are up to date -- everything before the
 // Q-head kernels (sample, window gathers, encoder) reads only E_in / W1 / W2 and may start earlier.
-// `presampled`: event after which this step's transitions and sorted pairs are already in place (sample_ahead).
-int sample_ahead(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+// `presampled`: event after which this step's transitions are already in place (sample_ahead); the sorted pairs the
+// backward needs follow under ss.sorted[step & 1].
+int sample_ahead(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, hipEvent_t sampled_ev) {
   const cqlrec_layout& L = c->layout;
   StepWs w = carve_step(c->ws, c->batch, L.n_items, L.d, c->window, step);
   CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
                                     (uint64_t)c->rank * (uint64_t)c->batch, c->batch, w.users, w.tpos, w.act, w.rew,
                                     w.done, stream));
+  CQL_HIP_TRY(hipEventRecord(sampled_ev, (hipStream_t)stream), "train_steps");
   CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, c->batch, c->window, L.d, L.n_items,
                                          w.ws_gb, w.ws_gb_bytes, stream));
   return cql_onehot_prepare(w.act, c->batch, L.n_items, L.d, w.ws_oh, w.ws_oh_bytes, (hipStream_t)stream);
@@ -249,22 +250,25 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   hipStream_t s = (hipStream_t)stream;
 
   SideStream& ss = side_stream();
+  // Data-parallel callers bring a side stream of their own and RCCL its internal one: there the two sorts ride on the
+  // branch stream behind branch B instead of occupying a stream (and a hardware queue) of their own.
+  const bool sort_on_branch = ss.ok && !presampled && c->world > 1;
   if (presampled) {
     CQL_HIP_TRY(hipStreamWaitEvent(s, presampled, 0), "train_step_forward");
   } else {
     // transitions of this rank's slots of the global step
     CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
                                       (uint64_t)c->rank * (uint64_t)B, B, w.users, w.tpos, w.act, w.rew, w.done, stream));
-    if (ss.ok) {
+    if (ss.ok && !sort_on_branch) {
       if (hipEventRecord(ss.forked, s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.forked, 0) != hipSuccess) ss.ok = false;
     }
   }
-  if (presampled) {
+  if (presampled || sort_on_branch) {
   } else if (ss.ok) {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            (cqlrec_stream)ss.s));
     CQL_TRY(cql_onehot_prepare(w.act, B, N, d, w.ws_oh, w.ws_oh_bytes, ss.s));
-    CQL_HIP_TRY(hipEventRecord(ss.joined, ss.s), "train_step_forward");
+    CQL_HIP_TRY(hipEventRecord(ss.sorted[step & 1], ss.s), "train_step_forward");
   } else {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            stream));
@@ -301,6 +305,11 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
     cql_set_error("train_step_forward: joining the forward branches failed");
     return CQLREC_ERR_HIP;
   }
+  if (sort_on_branch) {   // behind the join: the backward waits for ss.sorted, nothing in the forward does
+    CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, sb));
+    CQL_TRY(cql_onehot_prepare(w.act, B, N, d, w.ws_oh, w.ws_oh_bytes, (hipStream_t)sb));
+    CQL_HIP_TRY(hipEventRecord(ss.sorted[step & 1], (hipStream_t)sb), "train_step_forward");
+  }
   // loss + dQ coefficients
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
   CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, c->gamma, c->alpha, inv_batch, w.coef, w.y,
@@ -318,7 +327,7 @@ int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
   SideStream& ss = side_stream();
   // the (action, transition) pairs were sorted ahead of time on another stream (same event as the window pairs)
-  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.joined, 0), "train_step_backward_items");
+  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.sorted[step & 1], 0), "train_step_backward_items");
   // one-hot part first, as a deterministic segmented sum into the zeroed gradient rows; the long kernel accumulates
   static const bool atomic_scatter = getenv("CQL_ONEHOT_ATOMIC") && getenv("CQL_ONEHOT_ATOMIC")[0] == '1';   // A/B knob
   if (!atomic_scatter)
@@ -355,7 +364,7 @@ int backward_chain_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
   CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
                              c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
   SideStream& ss = side_stream();
-  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.joined, 0), "train_step_backward_rest");
+  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.sorted[step & 1], 0), "train_step_backward_rest");
   CQL_TRY(cqlrec_gather_pool_bwd_apply(w.dh0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, c->grads + L.off_E_in, stream));
   return CQLREC_OK;
 }
@@ -436,10 +445,11 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
     SideStream& ss = side_stream();
     if (g_mark_phase == 1) mark(MK_LOSS, s);
     if (ss.ok && hipEventRecord(ss.loss, s) == hipSuccess) {
-      if (i + 1 < n_steps && hipStreamWaitEvent(ss.s2, ss.loss, 0) == hipSuccess) {
-        // the next step's transitions depend on (seed, step) only: sample and sort them on the idle branch stream now
-        CQL_TRY(sample_ahead(c, step + 1, (cqlrec_stream)ss.s2));
-        CQL_HIP_TRY(hipEventRecord(ss.presample, ss.s2), "train_steps");
+      if (i + 1 < n_steps && hipStreamWaitEvent(ss.s3, ss.loss, 0) == hipSuccess) {
+        // the next step's transitions depend on (seed, step) only: sample them now, on a stream of their own, and sort
+        // the pairs its backward will need (two radix sorts, ~35 small launches) behind that
+        CQL_TRY(sample_ahead(c, step + 1, (cqlrec_stream)ss.s3, ss.presample));
+        CQL_HIP_TRY(hipEventRecord(ss.sorted[(step + 1) & 1], ss.s3), "train_steps");
         sampled = ss.presample;
       }
       CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.loss, 0), "train_steps");
