@@ -213,6 +213,17 @@ def main():
                                 "frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                                 "avg_ms": ms}
             topk["select_ms_per_pass"] = tk_ph["topk_select"][0] / reps
+        if tk_ph.get("gather_fwd", (0, 0))[1]:
+            # the window gather at a size that fills the chip: one launch over all `nu` users of the scoring pass
+            # (the training step's gathers cover only B = 4096 states and are launch/latency bound)
+            g_ms = tk_ph["gather_fwd"][0] / tk_ph["gather_fwd"][1]
+            lens_u = (off[1: nu + 1] - off[:nu]).clamp(max=L).float().mean().item()
+            gb = nu * (lens_u * d * 2 + lens_u * 4) + nu * d * 2        # rows + indices in, bf16 state out
+            topk["roofline_gather"] = {"bound": "hbm", "achieved": gb / (g_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": gb / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": g_ms,
+                                       "states_per_launch": nu,
+                                       "note": "E_in (25.6 MB) is Infinity-Cache resident: algorithmic bytes are "
+                                               "gathered rows, served mostly from cache"}
 
     if rank != 0:
         if world > 1:
