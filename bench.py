@@ -112,11 +112,28 @@ def main():
     U, NI, d, L, B, K = cfg["users"], cfg["items"], cfg["d"], cfg["window"], cfg["batch"], cfg["k"]
     lo, hi = rank * U // world, (rank + 1) * U // world
     off, items, rew = synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi)
-    # CQL_SHARD_OPTIMIZER=1: the row-sharded optimizer variant of the data-parallel step (opt-in, ranks > 1)
-    shard_opt = os.environ.get("CQL_SHARD_OPTIMIZER", "0") == "1"
-    core = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg,
-                   shard_optimizer=shard_opt)
-    core.set_log(off, items, rew)
+    # Ranks > 1: the row-sharded optimizer variant of the data-parallel step (reduce-scatter of the gradients, Adam on
+    # this rank's rows only, all-gather of the bf16 shadows: same bytes on the links as the all-reduce, 1/W of the Adam
+    # traffic).  CQL_SHARD_OPTIMIZER=0 selects the replicated all-reduce variant.  One probe step guards the choice: if
+    # the sharded step raises (it is verified bit for bit against the replicated one, but only through the gloo fallback
+    # of its two collectives), every rank falls back to the replicated variant.
+    shard_opt = world > 1 and os.environ.get("CQL_SHARD_OPTIMIZER", "1") != "0"
+
+    def make_core(shard):
+        c_ = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg,
+                     shard_optimizer=shard)
+        c_.set_log(off, items, rew)
+        return c_
+    core = make_core(shard_opt)
+    if core.shard_optimizer:
+        try:
+            core.train_steps(1)
+            torch.cuda.synchronize()
+        except Exception as exc:  # pragma: no cover - needs a multi-GPU RCCL job
+            print(f"[bench] rank {rank}: row-sharded optimizer step failed ({exc!r}); using the all-reduce variant",
+                  file=sys.stderr, flush=True)
+            del core
+            core = make_core(False)
 
     def barrier():
         if world > 1:
