@@ -16,6 +16,11 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a data-parallel rank has five that must
+# run concurrently (main, item side, forward branch, RCCL, torch's copy stream): ask for more before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import sys
 import time
 from pathlib import Path

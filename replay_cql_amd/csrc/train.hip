@@ -179,9 +179,9 @@ SideStream& side_stream() {
     // Plain streams, all of one priority class: mixing priority classes (tried: item-side backward low, branch stream
     // high) did not steer the dispatcher, and with a fifth stream in the process (the caller's side stream in the
     // data-parallel step) it serialised unrelated streams -- the phased step went from 0.28 to 0.64 ms at cfg2.
-    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) == hipSuccess &&
+    // s and s3 are created on first use (need_side_streams): a data-parallel job drives the item side on a stream of
+    // its own and never needs them, and HIP multiplexes streams onto few hardware queues -- an idle stream is not free
+    ss.ok = hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.sorted[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.sorted[1], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.forked, hipEventDisableTiming) == hipSuccess &&
@@ -194,6 +194,15 @@ SideStream& side_stream() {
             hipEventCreateWithFlags(&ss.presample, hipEventDisableTiming) == hipSuccess;
   }
   return ss;
+}
+
+// the streams only the single-rank drivers use
+bool need_side_streams(SideStream& ss) {
+  if (!ss.ok) return false;
+  if (!ss.s && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.s = nullptr;
+  if (!ss.s3 && hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) != hipSuccess) ss.s3 = nullptr;
+  if (!ss.s || !ss.s3) ss.ok = false;
+  return ss.ok;
 }
 
 struct StepPtrs {
@@ -259,7 +268,7 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
     // transitions of this rank's slots of the global step
     CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
                                       (uint64_t)c->rank * (uint64_t)B, B, w.users, w.tpos, w.act, w.rew, w.done, stream));
-    if (ss.ok && !sort_on_branch) {
+    if (ss.ok && !sort_on_branch && need_side_streams(ss)) {
       if (hipEventRecord(ss.forked, s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.forked, 0) != hipSuccess) ss.ok = false;
     }
   }
@@ -408,7 +417,7 @@ extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t ste
   // encoder and window-gather backward: latency / HBM bound).  Fork after the loss, join before returning.
   SideStream& ss = side_stream();
   hipStream_t s = (hipStream_t)stream;
-  if (ss.ok && hipEventRecord(ss.loss, s) == hipSuccess && hipStreamWaitEvent(ss.s, ss.loss, 0) == hipSuccess) {
+  if (need_side_streams(ss) && hipEventRecord(ss.loss, s) == hipSuccess && hipStreamWaitEvent(ss.s, ss.loss, 0) == hipSuccess) {
     CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));
     CQL_HIP_TRY(hipEventRecord(ss.items, ss.s), "train_step_fwd_bwd");
     CQL_TRY(backward_rest_impl(c, step, stream));
@@ -434,6 +443,7 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t pending = nullptr;   // item-side Adam of the previous step
   hipEvent_t sampled = nullptr;   // transitions + sorted pairs of this step, prepared during the previous backward
+  need_side_streams(side_stream());
   for (int32_t i = 0; i < n_steps; ++i) {
     const uint64_t step = step0 + (uint64_t)i;
     CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled));
