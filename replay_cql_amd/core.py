@@ -235,11 +235,12 @@ class CQLCore:
             # issue order matters: the collectives of one process group execute in the order they were issued (one
             # internal RCCL stream), so the state-side all-reduce -- whose gradients are ready first -- goes first and
             # runs under the item-side kernel; the item-side all-reduce queues behind it
-            work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):      # enqueue the long item-side kernel before the (slow to issue) collectives
                 side.wait_event(ev_fwd)
                 N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
                         "train_step_backward_items")
+            work_b = [self._allreduce_async(self.grads[0:lo_a]), self._allreduce_async(self.grads[hi_a:total])]
+            with torch.cuda.stream(side):
                 work_a = self._allreduce_async(self.grads[lo_a:hi_a])
             for w in work_b:
                 if w is not None:
@@ -324,24 +325,26 @@ class CQLCore:
             ev_fwd.record(main)
             N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
             ev_rest.record(main)
-            # state side first (its gradients are ready first; collectives of one group run in issue order)
-            w_in = reduce_scatter_sum(g_in, self.grads[P["in_region"][0]: P["in_region"][1]], pg, async_op=True)
-            w_t1, w_t2 = ar(*P["tail_in"]), ar(*P["tail_enc"])
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):      # the long item-side kernel is enqueued first: nothing below delays it
                 side.wait_event(ev_fwd)
                 N.check(self.lib.cqlrec_train_step_backward_items(C.byref(c), self.step, side.cuda_stream),
                         "train_step_backward_items")
-                w_out = reduce_scatter_sum(g_out, self.grads[P["out_region"][0]: P["out_region"][1]], pg, async_op=True)
-                w_t3 = ar(*P["tail_out"])
+            # Collectives of one group execute in the order they were issued (one internal RCCL stream).  State side first:
+            # its gradients are ready first, and its whole exchange (reduce-scatter, Adam on the own rows, all-gather
+            # of the shadows the next prologue reads) then runs under the item-side kernel; the item side queues behind.
+            w_in = reduce_scatter_sum(g_in, self.grads[P["in_region"][0]: P["in_region"][1]], pg, async_op=True)
+            w_t1, w_t2 = ar(*P["tail_in"]), ar(*P["tail_enc"])
             wait(w_in), wait(w_t1), wait(w_t2)
             self._adam_shard(P["in_own"][0], P["in_own"][1], g_in, s)
             upd(P["tail_in"][0], P["tail_in"][1], s)
             upd(P["tail_enc"][0], P["tail_enc"][1], s)
             self.grads[P["in_region"][0]: P["in_region"][1]].zero_()
-            for buf in (self.theta_b, self.target_b):
-                wait(all_gather_into(buf[P["in_region"][0]: P["in_region"][1]],
-                                     buf[P["in_own"][0]: P["in_own"][1]].clone(), pg, async_op=True))
+            w_ag = [all_gather_into(buf[P["in_region"][0]: P["in_region"][1]],
+                                    buf[P["in_own"][0]: P["in_own"][1]].clone(), pg, async_op=True)
+                    for buf in (self.theta_b, self.target_b)]
             with torch.cuda.stream(side):
+                w_out = reduce_scatter_sum(g_out, self.grads[P["out_region"][0]: P["out_region"][1]], pg, async_op=True)
+                w_t3 = ar(*P["tail_out"])
                 wait(w_out), wait(w_t3)
                 side.wait_event(ev_rest)   # the state-side backward reads rows of the E_out shadow
                 self._adam_shard(P["out_own"][0], P["out_own"][1], g_out, side.cuda_stream)
@@ -351,6 +354,8 @@ class CQLCore:
                     wait(all_gather_into(buf[P["out_region"][0]: P["out_region"][1]],
                                          buf[P["out_own"][0]: P["out_own"][1]].clone(), pg, async_op=True))
                 ev_items.record(side)
+            for w in w_ag:      # the next prologue (this stream) reads the gathered E_in shadows
+                wait(w)
             pending = True
             self.step += 1
         if pending:
