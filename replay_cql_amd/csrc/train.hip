@@ -179,8 +179,7 @@ SideStream& side_stream() {
     // Plain streams, all of one priority class: mixing priority classes (tried: item-side backward low, branch stream
     // high) did not steer the dispatcher, and with a fifth stream in the process (the caller's side stream in the
     // data-parallel step) it serialised unrelated streams -- the phased step went from 0.28 to 0.64 ms at cfg2.
-    // s and s3 are created on first use (need_side_streams): a data-parallel job drives the item side on a stream of
-    // its own and never needs them, and HIP multiplexes streams onto few hardware queues -- an idle stream is not free
+    // s and s3 are created on first use (need_side_streams)
     ss.ok = hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.sorted[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.sorted[1], hipEventDisableTiming) == hipSuccess &&
@@ -259,20 +258,17 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   hipStream_t s = (hipStream_t)stream;
 
   SideStream& ss = side_stream();
-  // Data-parallel callers bring a side stream of their own and RCCL its internal one: there the two sorts ride on the
-  // branch stream behind branch B instead of occupying a stream (and a hardware queue) of their own.
-  const bool sort_on_branch = ss.ok && !presampled && c->world > 1;
   if (presampled) {
     CQL_HIP_TRY(hipStreamWaitEvent(s, presampled, 0), "train_step_forward");
   } else {
     // transitions of this rank's slots of the global step
     CQL_TRY(cqlrec_sample_transitions(c->offsets, c->items, c->rewards, c->n_users, c->seed, step,
                                       (uint64_t)c->rank * (uint64_t)B, B, w.users, w.tpos, w.act, w.rew, w.done, stream));
-    if (ss.ok && !sort_on_branch && need_side_streams(ss)) {
+    if (ss.ok && need_side_streams(ss)) {
       if (hipEventRecord(ss.forked, s) != hipSuccess || hipStreamWaitEvent(ss.s, ss.forked, 0) != hipSuccess) ss.ok = false;
     }
   }
-  if (presampled || sort_on_branch) {
+  if (presampled) {
   } else if (ss.ok) {
     CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes,
                                            (cqlrec_stream)ss.s));
@@ -313,11 +309,6 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   if (par && (hipEventRecord(ss.join2, ss.s2) != hipSuccess || hipStreamWaitEvent(s, ss.join2, 0) != hipSuccess)) {
     cql_set_error("train_step_forward: joining the forward branches failed");
     return CQLREC_ERR_HIP;
-  }
-  if (sort_on_branch) {   // behind the join: the backward waits for ss.sorted, nothing in the forward does
-    CQL_TRY(cqlrec_gather_pool_bwd_prepare(c->offsets, c->items, w.users, w.tpos, 0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, sb));
-    CQL_TRY(cql_onehot_prepare(w.act, B, N, d, w.ws_oh, w.ws_oh_bytes, (hipStream_t)sb));
-    CQL_HIP_TRY(hipEventRecord(ss.sorted[step & 1], (hipStream_t)sb), "train_step_forward");
   }
   // loss + dQ coefficients
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
