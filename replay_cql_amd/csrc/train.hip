@@ -195,12 +195,12 @@ SideStream& side_stream() {
   return ss;
 }
 
-// the streams only the single-rank drivers use
-bool need_side_streams(SideStream& ss) {
+// streams created on first use: s (sorts of the forward; item side of the single-rank drivers) and s3 (sample-ahead of
+// cqlrec_train_steps only -- a data-parallel job never gets one)
+bool need_side_streams(SideStream& ss, bool want_s3 = false) {
   if (!ss.ok) return false;
-  if (!ss.s && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.s = nullptr;
-  if (!ss.s3 && hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) != hipSuccess) ss.s3 = nullptr;
-  if (!ss.s || !ss.s3) ss.ok = false;
+  if (!ss.s && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
+  if (ss.ok && want_s3 && !ss.s3 && hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
   return ss.ok;
 }
 
@@ -434,7 +434,7 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t pending = nullptr;   // item-side Adam of the previous step
   hipEvent_t sampled = nullptr;   // transitions + sorted pairs of this step, prepared during the previous backward
-  need_side_streams(side_stream());
+  need_side_streams(side_stream(), true);
   for (int32_t i = 0; i < n_steps; ++i) {
     const uint64_t step = step0 + (uint64_t)i;
     CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled));
