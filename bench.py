@@ -35,7 +35,15 @@ CONFIGS = {
     "cfg3": dict(users=1_000_000, items=100_000, d=128, window=50, batch=4096, k=10, topk_users=65_536),
     "cfg2": dict(users=100_000, items=10_000, d=64, window=50, batch=4096, k=10, topk_users=65_536),
     "tiny": dict(users=2_000, items=1_000, d=64, window=10, batch=256, k=10, topk_users=2_000),
+    # BASELINE.json configs[0] shape (MovieLens-1M: 6 040 users, 3 883 items, ~836 K events -> long histories)
+    "cfg1": dict(users=6_040, items=3_883, d=64, window=50, batch=4096, k=10, topk_users=6_040,
+                 mean_len=92.0, sigma=0.9, max_len=2000),
+    # BASELINE.json configs[4] as ONE GPU of the 8 sees it: the full 1 M-item, d=256 tables (512 MB each: beyond the
+    # Infinity Cache, the honest HBM case for the window gather) and 1/8 of the 10 M users
+    "cfg5shard": dict(users=1_250_000, items=1_000_000, d=256, window=50, batch=4096, k=10, topk_users=16_384),
 }
+WORKLOAD = {"cfg3": "BASELINE.json configs[2]", "cfg2": "BASELINE.json configs[1]", "cfg1": "BASELINE.json configs[0] shape",
+            "cfg5shard": "BASELINE.json configs[4], one GPU's share (users / 8, full tables)", "tiny": "tiny"}
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 
@@ -50,13 +58,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--dp-variant", default="auto", choices=["auto", "sharded", "allreduce"],
+                    help="ranks > 1: row-sharded optimizer (reduce-scatter / own-row Adam / bf16 all-gather), replicated "
+                         "Adam behind a gradient all-reduce, or auto = sharded behind ONE probe step whose outcome all "
+                         "ranks agree on (recorded in config.dp_variant / dp_probe)")
     ap.add_argument("--serial", action="store_true",
                     help="no intra-step concurrency for the whole run (per-kernel durations then match rocprofv3)")
     return ap.parse_args()
 
 
 def cpu_baseline(cfg, off, items, rew, budget_s=12.0):
-    """Oracle (numpy restatement, multi-threaded BLAS) on the host cores: identical algorithm, identical batch."""
+    """Oracle (numpy restatement, multi-threaded BLAS) on the host cores: identical algorithm, identical batch.
+    Returns the baseline object and what the parity check needs (initial parameters, per-step losses, top-K)."""
     import numpy as np
     from oracle import cql_oracle as O
     try:
@@ -65,21 +78,62 @@ def cpu_baseline(cfg, off, items, rew, budget_s=12.0):
     except Exception:  # pragma: no cover
         cores = os.cpu_count() or 1
     m = O.OracleModel.create(cfg["items"], cfg["d"], seed=7)
+    theta0 = m.theta.copy()
+    losses = []
     t0, n = time.perf_counter(), 0
     while n < 4 and (n == 0 or time.perf_counter() - t0 < budget_s):
         with np.errstate(all="ignore"):
-            O.train_steps(m, off, items, rew, 1, cfg["batch"], cfg["window"], seed=0, fast=True)
+            losses += O.train_steps(m, off, items, rew, 1, cfg["batch"], cfg["window"], seed=0, fast=True)
         n += 1
     dt = time.perf_counter() - t0
     # top-K on a small user sample
     nu = min(256, len(off) - 1)
     t1 = time.perf_counter()
-    O.predict_topk(m.layout, m.theta, off, items, np.arange(nu), cfg["k"], cfg["window"], filter_seen=True, fast=True)
+    tk = O.predict_topk(m.layout, m.theta, off, items, np.arange(nu), cfg["k"], cfg["window"], filter_seen=True, fast=True)
     dtk = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "train-steps/s", "cores": int(cores), "kind": "port",
+    base = {"value": n / dt, "unit": "train-steps/s", "cores": int(cores), "kind": "port",
             "sample": f"{n} oracle train steps (numpy, B={cfg['batch']}, N={cfg['items']}, d={cfg['d']}) on a "
                       f"{len(off) - 1}-user shard of the same synthetic log; top-K on {nu} users",
             "topk_users_per_s": nu / dtk}
+    return base, {"theta0": theta0, "losses": losses, "n": n, "nu": nu, "topk": tk[:3]}
+
+
+def parity_check(cfg, dev, d_off, d_items, d_rew, ref):
+    """The HIP path on the SAME shard, initial parameters, seed and steps as the oracle's cpu_baseline leg: per-step
+    losses (rtol 1e-3, P4) and the top-K lists of the trained model (P3 margin rule, 2e-3 because the two parameter
+    sets are 1e-3 apart after training).  Outside the timed region; reported, and `ok` summarises it."""
+    import numpy as np
+    from replay_cql_amd.core import CQLCore, CQLHyper
+    from replay_cql_amd.data import sorted_seen
+    core = CQLCore(cfg["items"], CQLHyper(d=cfg["d"], window=cfg["window"], batch=cfg["batch"], seed=0), device=dev)
+    core.load_flat(ref["theta0"])
+    core.set_log(d_off, d_items, d_rew)
+    g_losses = core.train(ref["n"]).cpu().numpy().astype(np.float64)
+    o_losses = np.asarray(ref["losses"], dtype=np.float64)
+    rel = np.abs(g_losses - o_losses) / np.abs(o_losses)
+    nu, k = ref["nu"], cfg["k"]
+    users = torch.arange(nu, dtype=torch.int32, device=dev)
+    seen = torch.as_tensor(np.concatenate([sorted_seen(d_off.cpu().numpy(), d_items.cpu().numpy()), [0]])
+                           .astype(np.int32)).to(dev)
+    hb = core.encode(d_off, d_items, users)
+    idx, val, cnt = (t.cpu().numpy() for t in core.score_topk(hb, k, seen=(d_off, seen), seen_rows=users))
+    ridx, rval, rcnt = ref["topk"]
+    same, worst, viol = 0, 0.0, 0
+    for u in range(nu):
+        got, want = dict(zip(idx[u], val[u])), dict(zip(ridx[u], rval[u]))
+        same += set(got) == set(want)
+        for j in got.keys() & want.keys():
+            worst = max(worst, abs(float(got[j]) - float(want[j])))
+        for j in got.keys() - want.keys():
+            viol += abs(float(got[j]) - float(rval[u, -1])) >= 2e-3
+        for j in want.keys() - got.keys():
+            viol += abs(float(want[j]) - float(val[u, -1])) >= 2e-3
+    ok = bool(rel.max() < 1e-3 and viol == 0 and worst < 2e-3 and np.array_equal(cnt, rcnt))
+    return {"ok": ok, "steps": int(ref["n"]), "gpu_losses": g_losses.tolist(), "oracle_losses": o_losses.tolist(),
+            "loss_max_rel_err": float(rel.max()), "loss_rtol": 1e-3,
+            "topk_users": int(nu), "topk_sets_identical": int(same), "topk_margin_violations": int(viol),
+            "topk_max_abs_score_diff": worst, "topk_margin": 2e-3,
+            "note": "oracle = this repo's CPU restatement (parity unpinned by the reference: it has no CQL path)"}
 
 
 def main():
@@ -116,29 +170,40 @@ def main():
     lib = N.load()
     U, NI, d, L, B, K = cfg["users"], cfg["items"], cfg["d"], cfg["window"], cfg["batch"], cfg["k"]
     lo, hi = rank * U // world, (rank + 1) * U // world
-    off, items, rew = synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi)
-    # Ranks > 1: the row-sharded optimizer variant of the data-parallel step (reduce-scatter of the gradients, Adam on
-    # this rank's rows only, all-gather of the bf16 shadows: same bytes on the links as the all-reduce, 1/W of the Adam
-    # traffic).  CQL_SHARD_OPTIMIZER=0 selects the replicated all-reduce variant.  One probe step guards the choice: if
-    # the sharded step raises (it is verified bit for bit against the replicated one, but only through the gloo fallback
-    # of its two collectives), every rank falls back to the replicated variant.
-    shard_opt = world > 1 and os.environ.get("CQL_SHARD_OPTIMIZER", "1") != "0"
+    gen_kw = {k_: cfg[k_] for k_ in ("mean_len", "sigma", "max_len") if k_ in cfg}
+    off, items, rew = synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi, **gen_kw)
+    # Ranks > 1, two exchange patterns with the same bytes on the links: "sharded" = reduce-scatter of the
+    # gradients, Adam on this rank's rows only, all-gather of the bf16 shadows (1/W of the Adam traffic per GPU);
+    # "allreduce" = replicated Adam behind a gradient all-reduce.  The variant is chosen by --dp-variant and the run
+    # FAILS if it does not work -- except under "auto", where one probe step of the sharded variant is tried first and
+    # ALL ranks agree (MAX all-reduce of a failure flag) whether to keep it; the outcome is part of the JSON line.
+    want = args.dp_variant if world > 1 else "single"
+    if os.environ.get("CQL_SHARD_OPTIMIZER") == "0":       # round-1 knob, kept
+        want = "allreduce" if world > 1 else want
+    dp_probe = None
 
     def make_core(shard):
         c_ = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg,
                      shard_optimizer=shard)
         c_.set_log(off, items, rew)
         return c_
-    core = make_core(shard_opt)
-    if core.shard_optimizer:
+    if want == "auto":
+        import torch.distributed as dist
+        failed, why = 0.0, ""
         try:
-            core.train_steps(1)
+            probe = make_core(True)
+            probe.train_steps(1)
             torch.cuda.synchronize()
         except Exception as exc:  # pragma: no cover - needs a multi-GPU RCCL job
-            print(f"[bench] rank {rank}: row-sharded optimizer step failed ({exc!r}); using the all-reduce variant",
-                  file=sys.stderr, flush=True)
-            del core
-            core = make_core(False)
+            failed, why = 1.0, repr(exc)
+            print(f"[bench] rank {rank}: row-sharded optimizer probe step failed: {why}", file=sys.stderr, flush=True)
+        flag = torch.tensor([failed], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        want = "allreduce" if float(flag.item()) > 0 else "sharded"
+        dp_probe = {"sharded_probe_failed_on_some_rank": bool(float(flag.item()) > 0), "rank0_error": why}
+        probe = None                                        # the probe step is discarded: the timed run starts fresh
+        torch.cuda.empty_cache()
+    core = make_core(want == "sharded")
 
     def barrier():
         if world > 1:
@@ -263,11 +328,12 @@ def main():
         "metric": "CQL train-steps/sec", "value": world * args.steps / dt, "unit": "train-steps/s (B=4096 transitions per step and GPU)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[2]: synthetic {U} users x {NI} items, CQL d={d}, L={L}, "
-                               f"B={B}/GPU, bf16 MFMA + fp32 accumulate" if args.config == "cfg3" else args.config,
+        "config": {"workload": f"{WORKLOAD[args.config]}: synthetic {U} users x {NI} items, CQL d={d}, L={L}, "
+                               f"B={B}/GPU, bf16 MFMA + fp32 accumulate",
                    "users": U, "items": NI, "d": d, "window": L, "batch_per_gpu": B, "global_batch": B * world,
                    "parallelism": f"dp{world} (users sharded by rank, RCCL gradient " +
-                                  ("reduce-scatter, row-sharded Adam, bf16 all-gather)" if core.shard_optimizer else "all-reduce)"), "k": K},
+                                  ("reduce-scatter, row-sharded Adam, bf16 all-gather)" if core.shard_optimizer else "all-reduce)"), "k": K,
+                   "dp_variant": want, "dp_probe": dp_probe},
         "transitions_per_sec": world * args.steps * B / dt,
         "loss_first_last": [losses[0], losses[-1]] if losses else None,
     }
@@ -328,9 +394,12 @@ def main():
         import numpy as np
         n_shard = min(hi - lo, 20_000)
         o_h = off[: n_shard + 1].cpu().numpy()
-        cb = cpu_baseline(cfg, o_h, items[: int(o_h[-1])].cpu().numpy(), rew[: int(o_h[-1])].cpu().numpy())
+        nz = int(o_h[-1])
+        cb, ref = cpu_baseline(cfg, o_h, items[:nz].cpu().numpy(), rew[:nz].cpu().numpy())
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = out["value"] / cb["value"]
+        out["parity_check"] = parity_check(cfg, dev, off[: n_shard + 1].contiguous(), items[:nz].contiguous(),
+                                           rew[:nz].contiguous(), ref)
     print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

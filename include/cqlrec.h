@@ -28,7 +28,7 @@ extern "C" {
 #define CQLREC_OK 0
 #define CQLREC_ERR_INVALID (-1)
 #define CQLREC_ERR_HIP (-2)
-#define CQLREC_ABI_VERSION 1
+#define CQLREC_ABI_VERSION 2
 #define CQLREC_SEG_ALIGN 64 /* every parameter segment starts on a multiple of 64 elements */
 
 typedef void* cqlrec_stream;
@@ -228,7 +228,9 @@ typedef struct cqlrec_train_ctx {
   int32_t window;       /* L */
   int32_t world;        /* data-parallel ranks (loss is a mean over batch*world) */
   int32_t rank;
-  float gamma, alpha, lr, beta1, beta2, eps, tau;
+  /* doubles: the Adam bias corrections 1 - beta^t are formed in double from the caller's values (as torch.optim.Adam
+   * does with its Python floats); the kernels receive them rounded to float */
+  double gamma, alpha, lr, beta1, beta2, eps, tau;
   uint64_t seed;
   /* scratch: cqlrec_train_ws_bytes(batch, n_items, d, window) bytes */
   void* ws;
@@ -288,6 +290,9 @@ int cqlrec_train_views_get(const cqlrec_train_ctx* ctx /* [host] */, uint64_t st
  * f2  log -> CSR by user on the device: rows sorted by (user_idx, timestamp asc, item_idx asc), S2.  Takes the place of
  * `log.toPandas()` + DataLoader construction (replay/models/neuromf.py:332-339).  Inputs are the LOG_SCHEMA columns
  * (replay/constants.py:16-23) as device arrays; timestamp in any monotone int64 unit.  Bit-exact vs a host lexsort.
+ * timestamp == NULL: rows ordered by (user_idx, item_idx asc) instead -- the per-user ascending `seen` lists that
+ * cqlrec_score_topk filters with (the role of the anti-join in _filter_seen, replay/models/base_rec.py:417-464).
+ * relevance == NULL (then rewards must be NULL too): no reward column is produced.
  * --------------------------------------------------------------------------------------------------------- */
 int64_t cqlrec_build_csr_ws_bytes(int64_t n_rows);
 int cqlrec_build_csr(const int32_t* user_idx, const int32_t* item_idx, const int64_t* timestamp,

@@ -14,11 +14,11 @@ _LIB_PATH = Path(os.environ["CQLREC_LIB"]).resolve() if os.environ.get("CQLREC_L
     Path(__file__).resolve().parent / "libcqlrec.so"
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 QHEAD_LSE = 1
 QHEAD_ARGMAX = 2
 
-vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
 
 class Layout(C.Structure):
@@ -46,7 +46,7 @@ class TrainCtx(C.Structure):
         ("theta", vp), ("grads", vp), ("adam_m", vp), ("adam_v", vp), ("target", vp), ("theta_b", vp),
         ("target_b", vp),
         ("batch", i32), ("window", i32), ("world", i32), ("rank", i32),
-        ("gamma", f32), ("alpha", f32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("tau", f32),
+        ("gamma", f64), ("alpha", f64), ("lr", f64), ("beta1", f64), ("beta2", f64), ("eps", f64), ("tau", f64),
         ("seed", u64),
         ("ws", vp), ("ws_bytes", i64),
     ]

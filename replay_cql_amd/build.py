@@ -14,6 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcqlrec.so"
+TORCH_LIB = PKG / "libcqlrec_torch.so"      # torch.ops.cqlrec.* registration shim over the C ABI (csrc/torch_ops.cpp)
 SOURCES = ["misc.hip", "qhead.hip", "topk.hip", "gbwd.hip", "prep.hip", "train.hip"]
 # misc.hip holds the Adam kernel whose expression order is normative: no fma contraction anywhere in that file
 EXTRA = {
@@ -33,11 +34,28 @@ def _hipcc() -> str:
 
 
 def _stale() -> bool:
-    if not LIB.exists():
+    if not LIB.exists() or not TORCH_LIB.exists():
         return True
-    t = LIB.stat().st_mtime
+    t = min(LIB.stat().st_mtime, TORCH_LIB.stat().st_mtime)
     deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "cqlrec.h", Path(__file__)]
     return any(p.stat().st_mtime > t for p in deps)
+
+
+def build_torch_ops(verbose: bool = True) -> Path:
+    """libcqlrec_torch.so: TORCH_LIBRARY(cqlrec) over the C ABI.  Host C++ only (no kernels): g++ against torch's headers,
+    linked to libcqlrec.so (rpath $ORIGIN) and to the torch libraries of THIS interpreter."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = Path(torch.__file__).resolve().parent / "lib"
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include"]
+    cmd += [str(CSRC / "torch_ops.cpp"), "-o", str(TORCH_LIB), f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+            f"-L{PKG}", "-lcqlrec", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return TORCH_LIB
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
@@ -62,6 +80,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    build_torch_ops(verbose)
     return LIB
 
 

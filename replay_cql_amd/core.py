@@ -139,6 +139,10 @@ class CQLCore:
             raise ValueError("inconsistent CSR: offsets[-1] must equal len(items) == len(rewards) and U >= 1")
         if items.numel() == 0:
             raise ValueError("empty log")
+        # the window gather reads E_in + item*d and both scatters write g_E_* + item*d unguarded: check the ids once
+        lo, hi = torch.stack([items.min(), items.max()]).cpu().tolist()
+        if lo < 0 or hi >= self.n_items:
+            raise ValueError(f"item ids must lie in [0, {self.n_items}); the log holds [{int(lo)}, {int(hi)}]")
         self._csr = (offsets, items, rewards)
         self._ctx = None
 

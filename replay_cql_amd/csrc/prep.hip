@@ -35,7 +35,7 @@ __global__ void csr_finish_kernel(const int32_t* __restrict__ user_idx, const in
   for (int64_t u = prev + 1; u <= cur; ++u) offsets[u] = i;
   if (i < n) {
     items[i] = item_idx[perm[i]];
-    rewards[i] = (float)relevance[perm[i]];
+    if (rewards) rewards[i] = (float)relevance[perm[i]];
   }
 }
 
@@ -46,7 +46,10 @@ extern "C" int64_t cqlrec_build_csr_ws_bytes(int64_t n_rows) {
 extern "C" int cqlrec_build_csr(const int32_t* user_idx, const int32_t* item_idx, const int64_t* timestamp,
                                 const double* relevance, int64_t n_rows, int64_t n_users, void* ws, int64_t ws_bytes,
                                 int64_t* offsets, int32_t* items, float* rewards, cqlrec_stream stream) {
-  CQL_REQUIRE(user_idx && item_idx && timestamp && relevance && ws && offsets && items && rewards, "build_csr: NULL pointer");
+  // timestamp == NULL: rows ordered by (user, item) -- the per-user ascending `seen` lists of cqlrec_score_topk;
+  // relevance == NULL (then rewards may be NULL too): no reward column is produced
+  CQL_REQUIRE(user_idx && item_idx && ws && offsets && items, "build_csr: NULL pointer");
+  CQL_REQUIRE((relevance != nullptr) == (rewards != nullptr), "build_csr: relevance and rewards go together");
   CQL_REQUIRE(n_rows > 0 && n_rows < (1ll << 32) && n_users > 0, "build_csr: n_rows=%lld n_users=%lld",
               (long long)n_rows, (long long)n_users);
   CQL_REQUIRE(ws_bytes >= cqlrec_build_csr_ws_bytes(n_rows), "build_csr: workspace too small");
@@ -93,6 +96,7 @@ extern "C" int cqlrec_build_csr(const int32_t* user_idx, const int32_t* item_idx
     return CQLREC_OK;
   };
   for (int w = 0; w < 3; ++w) {
+    if (w == 1 && !timestamp) continue;
     const int rc = pass(w);
     if (rc != CQLREC_OK) return rc;
   }

@@ -208,6 +208,8 @@ struct StepPtrs {
   const uint16_t *Ein_b, *Eout_b, *W1_b, *W2_b, *tEin_b, *tEout_b, *tW1_b, *tW2_b;
   const float *b_out, *b1, *b2, *tb_out, *tb1, *tb2;
 };
+// alpha / (global batch), formed in double and rounded once (the oracle's np.float32(alpha / Bg))
+float alpha_scale(const cqlrec_train_ctx* c) { return (float)(c->alpha / ((double)c->batch * (double)c->world)); }
 StepPtrs step_ptrs(const cqlrec_train_ctx* c) {
   const cqlrec_layout& L = c->layout;
   StepPtrs p;
@@ -312,7 +314,7 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   }
   // loss + dQ coefficients
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
-  CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, c->gamma, c->alpha, inv_batch, w.coef, w.y,
+  CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, (float)c->gamma, (float)c->alpha, inv_batch, w.coef, w.y,
                          loss_out ? loss_out : w.loss, stream));
   if (g_mark_phase == 2) mark(MK_NEXT_LOSS, s);
   return CQLREC_OK;
@@ -324,7 +326,6 @@ int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
   const int32_t B = c->batch, d = L.d;
   StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
-  const float inv_batch = 1.0f / ((float)B * (float)c->world);
   SideStream& ss = side_stream();
   // the (action, transition) pairs were sorted ahead of time on another stream (same event as the window pairs)
   if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.sorted[step & 1], 0), "train_step_backward_items");
@@ -333,7 +334,7 @@ int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
   if (!atomic_scatter)
     CQL_TRY(cql_onehot_apply(w.coef, w.hb, B, L.n_items, d, w.ws_oh, c->grads + L.off_E_out, c->grads + L.off_b_out,
                              (hipStream_t)stream));
-  return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, c->alpha * inv_batch,
+  return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, alpha_scale(c),
                                  w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
                                  (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1);
 }
@@ -345,9 +346,8 @@ int backward_states_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream
   const int64_t N = L.n_items;
   StepWs w = carve_step(c->ws, B, N, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
-  const float inv_batch = 1.0f / ((float)B * (float)c->world);
   // the catalogue pass was done by the forward: only the slabs are combined here (scale, exp(m - lse), + coef * E[a])
-  CQL_TRY(cql_qhead_dh_finish(w.ws_qb, B, N, d, w.lse, w.coef, w.act, p.Eout_b, c->alpha * inv_batch, w.dH,
+  CQL_TRY(cql_qhead_dh_finish(w.ws_qb, B, N, d, w.lse, w.coef, w.act, p.Eout_b, alpha_scale(c), w.dH,
                               (hipStream_t)stream));
   SideStream& ss = side_stream();
   if (ss.ok) CQL_HIP_TRY(hipEventRecord(ss.dh, (hipStream_t)stream), "train_step_backward_rest");
@@ -491,7 +491,8 @@ extern "C" int cqlrec_train_step_update_range(const cqlrec_train_ctx* c, uint64_
   const float step_size = (float)((double)c->lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
   return cqlrec_adam_ema(c->theta + lo, c->grads + lo, c->adam_m + lo, c->adam_v + lo, c->target + lo, c->theta_b + lo,
-                         c->target_b + lo, hi - lo, step_size, sqrt_bc2, c->beta1, c->beta2, c->eps, c->tau, 1, stream);
+                         c->target_b + lo, hi - lo, step_size, sqrt_bc2, (float)c->beta1, (float)c->beta2, (float)c->eps, (float)c->tau, 1,
+                         stream);
 }
 
 extern "C" int cqlrec_train_step_update(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {

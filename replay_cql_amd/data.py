@@ -11,15 +11,41 @@ import numpy as np
 import torch
 
 
+_I64_LOW63 = 0x7FFFFFFFFFFFFFFF
+
+
+def timestamp_key(timestamp):
+    """LOG_SCHEMA `timestamp` column (datetime64, integer or float; numpy or torch) -> int64 keys whose signed order is
+    the column's order.  Floats go through the IEEE total-order map (sign-magnitude -> two's complement), with -0.0
+    folded onto +0.0, so fractional timestamps keep their order -- the SAME keys feed the host lexsort (build_csr) and
+    the device radix sort (build_csr_device), which keeps fit and predict on one event order.  NaN is rejected."""
+    if torch.is_tensor(timestamp):
+        if not timestamp.dtype.is_floating_point:
+            return timestamp.to(torch.int64)
+        a = timestamp.to(torch.float64) + 0.0
+        if bool(torch.isnan(a).any()):
+            raise ValueError("timestamp contains NaN")
+        b = a.view(torch.int64)
+        return torch.where(b < 0, b ^ _I64_LOW63, b)
+    a = np.asarray(timestamp)
+    if a.dtype.kind == "M":
+        return a.astype("datetime64[ns]").astype(np.int64)
+    if a.dtype.kind in "iu":
+        return a.astype(np.int64)
+    if a.dtype.kind != "f":
+        return a.astype("datetime64[ns]").astype(np.int64)
+    a = a.astype(np.float64) + 0.0
+    if np.isnan(a).any():
+        raise ValueError("timestamp contains NaN")
+    b = a.view(np.int64)
+    return np.where(b < 0, b ^ np.int64(_I64_LOW63), b)
+
+
 def build_csr(user_idx, item_idx, timestamp, relevance, n_users: Optional[int] = None):
     """Sort by (user, timestamp asc, item_idx asc) -> offsets int64[U+1], items int32[nnz], rewards float32[nnz]."""
     user_idx = np.asarray(user_idx, dtype=np.int64)
     item_idx = np.asarray(item_idx, dtype=np.int64)
-    timestamp = np.asarray(timestamp)
-    if timestamp.dtype.kind == "M":
-        timestamp = timestamp.astype("datetime64[ns]").astype(np.int64)
-    elif timestamp.dtype.kind not in "iuf":
-        timestamp = timestamp.astype("datetime64[ns]").astype(np.int64)
+    timestamp = timestamp_key(timestamp)
     relevance = np.asarray(relevance, dtype=np.float64)
     if not (len(user_idx) == len(item_idx) == len(timestamp) == len(relevance)):
         raise ValueError("log columns differ in length")
@@ -95,35 +121,40 @@ def synth_log_device(n_users: int, n_items: int, seed: int = 12345, device="cuda
     return offsets, items.contiguous(), rewards.contiguous()
 
 
-def build_csr_device(user_idx, item_idx, timestamp, relevance, n_users: int, device="cuda"):
-    """build_csr on the GPU (cqlrec_build_csr: three stable rocPRIM radix sorts + boundary scan); returns device
-    tensors (offsets int64[U+1], items int32[nnz], rewards float32[nnz]).  Bit-identical to build_csr()."""
+def _dev_col(x, dt, dev):
+    if torch.is_tensor(x):
+        return x.to(device=dev, dtype=dt).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x))).to(device=dev, dtype=dt).contiguous()
+
+
+def build_csr_device(user_idx, item_idx, timestamp, relevance, n_users: int, device="cuda", check: bool = True):
+    """build_csr on the GPU (cqlrec_build_csr: stable rocPRIM radix sorts + boundary scan); returns device tensors
+    (offsets int64[U+1], items int32[nnz], rewards float32[nnz]).  Bit-identical to build_csr().
+
+    timestamp=None: rows ordered by (user, item asc) -- the `seen` lists of cqlrec_score_topk (sorted_seen() on the
+    device).  relevance=None: no reward column (returns rewards=None)."""
     from . import _native as N
     lib = N.load()
     dev = torch.device(device)
-
-    def col(x, dt):
-        if torch.is_tensor(x):
-            return x.to(device=dev, dtype=dt).contiguous()
-        a = np.asarray(x)
-        if a.dtype.kind == "M":
-            a = a.astype("datetime64[ns]").astype(np.int64)
-        return torch.as_tensor(np.ascontiguousarray(a)).to(device=dev, dtype=dt).contiguous()
-    u, i = col(user_idx, torch.int32), col(item_idx, torch.int32)
-    t, r = col(timestamp, torch.int64), col(relevance, torch.float64)
+    u, i = _dev_col(user_idx, torch.int32, dev), _dev_col(item_idx, torch.int32, dev)
+    t = None if timestamp is None else _dev_col(timestamp_key(timestamp), torch.int64, dev)
+    r = None if relevance is None else _dev_col(relevance, torch.float64, dev)
     n = u.numel()
-    if not (n == i.numel() == t.numel() == r.numel()):
+    if n != i.numel() or (t is not None and t.numel() != n) or (r is not None and r.numel() != n):
         raise ValueError("log columns differ in length")
     offsets = torch.zeros(n_users + 1, dtype=torch.int64, device=dev)
     items = torch.empty(n, dtype=torch.int32, device=dev)
-    rewards = torch.empty(n, dtype=torch.float32, device=dev)
+    rewards = None if r is None else torch.empty(n, dtype=torch.float32, device=dev)
     if n == 0:
         return offsets, items, rewards
-    if int(u.min()) < 0 or int(i.min()) < 0 or int(u.max()) >= n_users:
-        raise ValueError("user_idx / item_idx must be non-negative dense indices below n_users")
+    if check:
+        lo = torch.minimum(u.min(), i.min())
+        if int(lo) < 0 or int(u.max()) >= n_users:
+            raise ValueError("user_idx / item_idx must be non-negative dense indices below n_users")
     ws_bytes = int(lib.cqlrec_build_csr_ws_bytes(n))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    N.check(lib.cqlrec_build_csr(u.data_ptr(), i.data_ptr(), t.data_ptr(), r.data_ptr(), n, n_users, ws.data_ptr(),
-                                 ws_bytes, offsets.data_ptr(), items.data_ptr(), rewards.data_ptr(),
+    N.check(lib.cqlrec_build_csr(u.data_ptr(), i.data_ptr(), None if t is None else t.data_ptr(),
+                                 None if r is None else r.data_ptr(), n, n_users, ws.data_ptr(), ws_bytes,
+                                 offsets.data_ptr(), items.data_ptr(), None if rewards is None else rewards.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream), "build_csr")
     return offsets, items, rewards

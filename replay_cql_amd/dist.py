@@ -59,6 +59,18 @@ def max_over_ranks(value: float, device, group=None) -> float:
     return float(t.item())
 
 
+def sum_over_ranks(value: float, device, group=None) -> float:
+    """SUM of a host scalar over the ranks (identity when not distributed): epoch length from the global log size,
+    validation loss agreed across ranks (CQL.fit_arrays)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    dev = device if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item())
+
+
 def reduce_scatter_sum(out: torch.Tensor, region: torch.Tensor, group=None, async_op: bool = False):
     """out = this rank's 1/W slice of the SUM over ranks of `region` (numel = W * out.numel()).  RCCL: one
     reduce-scatter.  gloo has none: all-reduce the region and keep the own slice (same sums; used by the tests that run

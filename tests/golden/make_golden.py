@@ -18,30 +18,41 @@ CASES = {
     "small_random": (64, 257, 64, 5, 32, 4, False, 2),
     "small_dyadic": (64, 257, 64, 5, 32, 1, True, 2),
     "medium_random": (300, 1000, 128, 8, 64, 3, False, 3),
+    # the SURVEY 8(c) "medium" fixture: U=2048, N=10007, d=64, L=50
+    "survey_medium_random": (2048, 10007, 64, 50, 256, 3, False, 4),
+    "survey_medium_dyadic": (2048, 10007, 64, 50, 256, 1, True, 4),
 }
 
 
 def make(name):
     U, Nn, d, L, B, steps, dyadic, ls = CASES[name]
-    u, i, t, r = O.synth_log(U, Nn, seed=ls, mean_len=6 if U < 10 else 14, min_len=3, max_len=45)
+    big = U >= 2048      # long histories, so that the L=50 window is really full for most states
+    u, i, t, r = O.synth_log(U, Nn, seed=ls, mean_len=6 if U < 10 else (40 if big else 14), min_len=3,
+                             max_len=120 if big else 45)
     off, items, rew = O.build_csr(u, i, t, r, U)
     m = O.OracleModel.create(Nn, d, seed=7, dyadic=dyadic)
+    stride = max(1, m.layout.total // 257)
+    theta0_probe = m.theta[::stride][:257].copy()
+    k = min(10, Nn)
+    # top-K of the INITIAL parameters (dyadic cases: ids, order and scores are exact) for the first 256 users
+    nu0 = min(U, 256)
+    idx0, val0, cnt0, _ = O.predict_topk(m.layout, m.theta, off, items, np.arange(nu0), k, L, filter_seen=True)
     pos = O.sample_positions(11, 0, 0, B, int(off[-1]))
     users, tpos = O.positions_to_transitions(pos, off)
     out = O.loss_and_grads(m.layout, m.theta, m.target, off, items, rew, users, tpos, L, 0.99, 1.0)
     losses = O.train_steps(m, off, items, rew, steps, B, L, seed=11)
-    k = min(10, Nn)
     idx, val, cnt, _ = O.predict_topk(m.layout, m.theta, off, items, np.arange(U), k, L, filter_seen=True)
     lay = m.layout
     np.savez_compressed(
         OUT / f"{name}.npz",
         case=np.array([U, Nn, d, L, B, steps, int(dyadic), ls]),
-        log_user=u, log_item=i, log_ts=t, log_rel=r,
+        log_user=u.astype(np.int32), log_item=i.astype(np.int32), log_ts=t.astype(np.int32), log_rel=r.astype(np.float32),
+        theta0_probe=theta0_probe, topk0_idx=idx0, topk0_val=val0, topk0_cnt=cnt0,
         users=users, tpos=tpos, q_a=out.q_a, lse=out.lse, a_star=out.a_star, q_targ=out.q_targ, y=out.y,
         loss0=np.float64(out.loss), grad_norms=np.array([np.linalg.norm(lay.view(out.grads, n)) for n in
                                                          ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2")]),
         losses=np.array(losses), theta_sum=np.float64(m.theta.astype(np.float64).sum()),
-        theta_probe=m.theta[:: max(1, lay.total // 257)][:257].copy(),
+        theta_probe=m.theta[::stride][:257].copy(),
         topk_idx=idx, topk_val=val, topk_cnt=cnt)
 
 

@@ -100,6 +100,8 @@ def _rs_ag_worker(rank, world, port, q):
     PD.reduce_scatter_sum(mine, region, pg)
     full = torch.zeros(world * n)
     PD.all_gather_into(full, mine * 2, pg)
+    # epoch length agreed from the GLOBAL log size (CQL.fit_arrays): unequal local sizes, one answer on every rank
+    assert PD.sum_over_ranks(float(1000 + 7 * rank), "cpu", pg) == float(sum(1000 + 7 * r_ for r_ in range(world)))
     q.put((rank, mine.numpy().copy(), full.numpy().copy()))
     dist.destroy_process_group()
 

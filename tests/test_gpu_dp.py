@@ -114,3 +114,47 @@ def test_two_ranks_one_gpu_match_oracle():
         ref_losses.append(loss)
     np.testing.assert_allclose(res[0][2], ref_losses, rtol=1e-3)
     assert np.linalg.norm(res[0][1] - m.theta) < 1e-3 * np.linalg.norm(m.theta)
+
+
+def _fit_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from replay_cql_amd import dist as PD
+    from replay_cql_amd.cql import CQL
+    r, w, pg = PD.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    off, items, rew = _data()
+    cut = int(U * 0.62)                       # UNEQUAL shards: a per-rank epoch length would differ between the ranks
+    lo, hi = (0, cut) if rank == 0 else (cut, U)
+    m = CQL(embedding_dim=D_, window=L, batch_size=B, epochs=3, valid_split_size=0.2, patience=0, factor=0.5, seed=5,
+            device="cuda:0")
+    m.set_distributed(rank, world, pg)
+    m.fit_arrays(*_shard(off, items, rew, lo, hi), NI)
+    q.put((rank, m.core.theta.cpu().numpy(), m.train_losses, m.valid_losses, m.best_epoch, m.core.hyper.lr,
+           int(_shard(off, items, rew, lo, hi - int((hi - lo) * 0.2))[0][-1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_arrays_data_parallel_unequal_shards():
+    """CQL.fit_arrays under data parallelism -- the epoch length comes from the GLOBAL log size (all ranks
+    issue the same number of all-reduces), the validation loss, the plateau cut and the best-epoch choice are agreed
+    across ranks: replicas end bit-identical, with identical bookkeeping."""
+    import math
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = res
+    assert a[6] != b[6]                                           # the local training logs really differ in size
+    steps = 3 * math.ceil((a[6] + b[6]) / (B * world))
+    assert len(a[2]) == len(b[2]) == steps
+    assert np.array_equal(a[1], b[1])                             # replicas bit-identical
+    assert np.array_equal(a[3], b[3]) and a[4] == b[4] and a[5] == b[5]
+    assert np.allclose(a[2], b[2])                                # the reduced loss

@@ -11,7 +11,8 @@ import torch
 from oracle import cql_oracle as O
 from replay_cql_amd import _native as N
 
-from helpers import DEV, bf16_dev, bf16_to_np, dev, ptr, rel_err, small_log, stream, sync, ws_bytes_tensor
+from helpers import (DEV, bf16_dev, bf16_to_np, dev, ptr, qhead_inputs as _qhead_inputs, rel_err, small_log, stream, sync,
+                     topk_case as _topk_case, ws_bytes_tensor)
 
 pytestmark = pytest.mark.gpu
 
@@ -206,19 +207,6 @@ def test_encoder_bwd(lib, d, rows):
 
 
 # ------------------------------------------------------------------------------------------------ Q-head forward
-def _qhead_inputs(rows, Nn, d, dyadic, seed):
-    rng = np.random.default_rng(seed)
-    if dyadic:
-        H = (rng.integers(-8, 9, (rows, d)) / 8.0).astype(np.float32)
-        E = (rng.integers(-8, 9, (Nn, d)) / 8.0).astype(np.float32)
-        b = (rng.integers(-16, 17, Nn) / 8.0).astype(np.float32)
-    else:
-        H = rng.standard_normal((rows, d)).astype(np.float32)
-        E = (rng.standard_normal((Nn, d)) / np.sqrt(d)).astype(np.float32)
-        b = (rng.standard_normal(Nn) * 0.3).astype(np.float32)
-    return O.bf16_round(H), O.bf16_round(E), b
-
-
 QSHAPES = [(1, 5, 64), (33, 257, 64), (100, 1000, 128), (257, 4099, 128), (70, 513, 256), (512, 10007, 64)]
 
 
@@ -417,50 +405,6 @@ def test_adam_bit_exact(lib):
 
 
 # ------------------------------------------------------------------------------------------------ top-K
-def _topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None):
-    Hb, Eb, b = _qhead_inputs(n_users, Nn, d, dyadic, seed)
-    rng = np.random.default_rng(seed)
-    ids = np.arange(Nn, dtype=np.int32) if cand is None else cand
-    E_c, b_c = Eb[ids], b[ids]
-    Q = O.qvalues(Hb, E_c, b_c)
-    seen_off = seen_items = None
-    if with_seen:
-        cnts = rng.integers(0, 40, n_users)
-        cnts[0] = 0
-        seen_off = np.zeros(n_users + 1, dtype=np.int64)
-        np.cumsum(cnts, out=seen_off[1:])
-        rows = []
-        for u in range(n_users):
-            top = np.argsort(-Q[u])[: cnts[u] // 2]                   # half of the seen items are the best ones
-            rnd = rng.integers(0, Nn, cnts[u] - len(top))
-            row = np.unique(np.concatenate([ids[top], rnd]).astype(np.int32))
-            rows.append(row)
-            seen_off[u + 1] = seen_off[u] + len(row)
-        seen_items = np.concatenate(rows).astype(np.int32) if rows else np.zeros(0, np.int32)
-        pos_of = -np.ones(Nn, dtype=np.int64)
-        pos_of[ids] = np.arange(len(ids))
-        for u in range(n_users):
-            p = pos_of[seen_items[seen_off[u]: seen_off[u + 1]]]
-            Q[u, p[p >= 0]] = -np.inf
-    kk = min(k, len(ids))
-    idx_c, val_ref = O.topk_rows(Q, kk)
-    idx_ref = np.where(np.isfinite(val_ref), ids[idx_c], -1)
-
-    nb = int(lib.cqlrec_topk_ws_bytes(n_users, len(ids), d, k))
-    ws = ws_bytes_tensor(nb)
-    out_idx = torch.empty((n_users, k), dtype=torch.int32, device=DEV)
-    out_val = torch.empty((n_users, k), dtype=torch.float32, device=DEV)
-    out_cnt = torch.empty(n_users, dtype=torch.int32, device=DEV)
-    d_ids = None if cand is None else dev(ids)
-    d_so = None if seen_off is None else dev(seen_off)
-    d_si = None if seen_items is None else dev(np.concatenate([seen_items, np.zeros(1, np.int32)]))
-    N.check(lib.cqlrec_score_topk(ptr(bf16_dev(Hb)), n_users, ptr(bf16_dev(E_c)), ptr(dev(b_c)), len(ids), d, ptr(d_ids),
-                                  ptr(d_so), ptr(d_si), None, k, ptr(ws), nb, ptr(out_idx), ptr(out_val), ptr(out_cnt),
-                                  stream()))
-    sync()
-    return out_idx.cpu().numpy(), out_val.cpu().numpy(), out_cnt.cpu().numpy(), idx_ref, val_ref, Q
-
-
 @pytest.mark.parametrize("n_users,Nn,d,k", [(5, 40, 64, 10), (70, 1000, 128, 10), (130, 4099, 64, 25),
                                             (33, 10007, 128, 100), (20, 513, 256, 7), (9, 3000, 64, 700),
                                             (6, 2500, 128, 2048)])

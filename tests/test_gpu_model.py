@@ -173,3 +173,70 @@ def test_on_device_evaluation_matches_reference_metric_definitions(log, model):
     for m, d in ref.items():
         for k, v in d.items():
             assert got[name[m]][k] == pytest.approx(v, rel=1e-9, abs=1e-12), (m, k)
+
+
+def _arrow_log(log, chunk=500):
+    import pyarrow as pa
+    tbl = pa.table({"user_idx": pa.array(log.user_idx.to_numpy().astype(np.int32)),
+                    "item_idx": pa.array(log.item_idx.to_numpy().astype(np.int32)),
+                    "timestamp": pa.array(log.timestamp.to_numpy().astype("datetime64[us]")),
+                    "relevance": pa.array(log.relevance.to_numpy().astype(np.float64))})
+    return tbl.to_batches(max_chunksize=chunk)
+
+
+def test_arrow_fit_and_predict_equal_the_pandas_path(log, model):
+    """f1: Arrow record batches in, one REC_SCHEMA batch out -- same bookkeeping, same training trajectory (bit for
+    bit: the step is deterministic), same recommendations as fit()/predict() on the pandas frame."""
+    from replay_cql_amd import arrow_io as A
+    batches = _arrow_log(log)
+    assert len(batches) > 1
+    model = CQL(embedding_dim=D_, window=L, batch_size=64, n_steps=12, seed=3, device="cuda:0")
+    model.fit(log)                    # a fresh pandas-path twin (the shared fixture is trained further by other tests)
+    m2 = CQL(embedding_dim=D_, window=L, batch_size=64, n_steps=12, seed=3, device="cuda:0")
+    m2.fit_arrow(batches)
+    assert (m2._num_users, m2._num_items, m2._user_dim_size, m2._item_dim_size) == \
+        (model._num_users, model._num_items, model._user_dim_size, model._item_dim_size)
+    assert np.array_equal(np.sort(m2.fit_items.item_idx.values), np.sort(model.fit_items.item_idx.values))
+    assert np.array_equal(m2.train_losses, model.train_losses)
+    assert torch.equal(m2.core.theta, model.core.theta)
+    k = 7
+    want = model.predict(log, k=k)
+    rb = m2.predict_arrow(batches, k)
+    assert rb.schema.equals(A.REC_SCHEMA)
+    got = rb.to_pandas()
+    pd.testing.assert_frame_equal(got, want.sort_values(["user_idx", "relevance", "item_idx"], ascending=[True, False, True],
+                                                       kind="stable").reset_index(drop=True))
+    # users / items subsets, unseen ids dropped as _filter_cold_for_predict does; no seen filter
+    want = model.predict(log, k=3, users=[0, 5, 9, 10_000], items=[1, 2, 3, 4, 5, 6, 10**6], filter_seen_items=False)
+    got = m2.predict_arrow(batches, 3, users=[0, 5, 9, 10_000], items=[1, 2, 3, 4, 5, 6, 10**6],
+                           filter_seen_items=False).to_pandas()
+    pd.testing.assert_frame_equal(got, want.reset_index(drop=True))
+    # a log without timestamps is legal for predict: event order = row order
+    import pyarrow as pa
+    srt = log.sort_values(["user_idx", "timestamp", "item_idx"], kind="stable")
+    no_ts = pa.table({"user_idx": pa.array(srt.user_idx.to_numpy().astype(np.int32)),
+                      "item_idx": pa.array(srt.item_idx.to_numpy().astype(np.int32))})
+    pd.testing.assert_frame_equal(m2.predict_arrow(no_ts, k).to_pandas(), rb.to_pandas())
+
+
+def test_out_of_range_item_ids_raise_before_any_kernel(log, model):
+    """ids >= n_items would be an out-of-bounds gather / scatter; every array entry point checks them."""
+    from replay_cql_amd.core import CQLCore, CQLHyper
+    core = CQLCore(50, CQLHyper(d=64, window=4, batch=32), device="cuda:0")
+    off = np.array([0, 3, 5], dtype=np.int64)
+    with pytest.raises(ValueError, match="item ids"):
+        core.set_log(off, np.array([1, 2, 50, 3, 4], dtype=np.int32), np.ones(5, np.float32))
+    with pytest.raises(ValueError, match="item ids"):
+        core.set_log(off, np.array([1, 2, -1, 3, 4], dtype=np.int32), np.ones(5, np.float32))
+    bad = pd.concat([log, pd.DataFrame({"user_idx": [0], "item_idx": [model._item_dim_size + 3],
+                                        "timestamp": [log.timestamp.max()], "relevance": [1.0]})], ignore_index=True)
+    with pytest.raises(ValueError, match="fitted on"):       # _predict called directly, as scenarios do
+        model._predict(bad, 3, pd.DataFrame({"user_idx": [0]}), model.fit_items)
+    # the wrapper filters cold items out of the log first (base_rec.py:560-603): same recommendations as without the row
+    pd.testing.assert_frame_equal(model.predict(bad, k=3, users=[0, 1]), model.predict(log, k=3, users=[0, 1]))
+    # evaluate() takes a test-period log with unseen users and items
+    test = log.sample(frac=0.1, random_state=2)[["user_idx", "item_idx"]]
+    bad2 = pd.concat([bad, pd.DataFrame({"user_idx": [model._user_dim_size + 5], "item_idx": [1],
+                                         "timestamp": [log.timestamp.max()], "relevance": [1.0]})], ignore_index=True)
+    a, b = model.evaluate(bad2, test, ks=[5]), model.evaluate(log, test, ks=[5])
+    assert a == b

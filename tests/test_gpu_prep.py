@@ -40,6 +40,28 @@ def test_build_csr_device_datetime_and_validation():
         D.build_csr_device([0, 5], [1, 2], [0, 1], [1.0, 1.0], 2, device=DEV)
 
 
+def test_build_csr_device_float_timestamps_and_seen_lists():
+    """Fractional float timestamps order like the host lexsort (no int64 truncation); timestamp=None gives the
+    per-user ascending seen lists (== data.sorted_seen), relevance=None drops the reward column."""
+    rng = np.random.default_rng(5)
+    n, U, NI = 200_000, 3_000, 700
+    u, i = rng.integers(0, U, n).astype(np.int32), rng.integers(0, NI, n).astype(np.int32)
+    t = np.round(rng.standard_normal(n) * 5, 2)             # ties, negatives, fractions within one unit
+    r = rng.integers(1, 6, n) / 5.0
+    off, items, rew = D.build_csr_device(u, i, t, r, U, device=DEV)
+    ro, ri, rr = O.build_csr(u, i, t, r, U)
+    assert np.array_equal(off.cpu().numpy(), ro) and np.array_equal(items.cpu().numpy(), ri)
+    assert np.array_equal(rew.cpu().numpy(), rr)
+    # device tensors in, float32 timestamps
+    o2, i2, _ = D.build_csr_device(torch.as_tensor(u).to(DEV), torch.as_tensor(i).to(DEV),
+                                   torch.as_tensor(t.astype(np.float32)).to(DEV), r, U, device=DEV)
+    h2 = D.build_csr(u, i, t.astype(np.float32), r, U)
+    assert np.array_equal(o2.cpu().numpy(), h2[0]) and np.array_equal(i2.cpu().numpy(), h2[1])
+    so, si, sr = D.build_csr_device(u, i, None, None, U, device=DEV)
+    assert sr is None and np.array_equal(so.cpu().numpy(), ro)
+    assert np.array_equal(si.cpu().numpy(), D.sorted_seen(ro, ri))
+
+
 def _block_from_frames(recs, true, users, kmax):
     rec = -np.ones((len(users), kmax), dtype=np.int32)
     for row, u in enumerate(users):

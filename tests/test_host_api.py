@@ -142,3 +142,63 @@ def test_synthetic_generator_is_shardable_and_deterministic():
     assert set(np.round(rew.unique().numpy().astype(np.float64), 4).tolist()) <= {0.2, 0.4, 0.6, 0.8, 1.0}
     o3, i3, _ = D.synth_log_device(3000, 500, seed=10, device="cpu")
     assert not torch.equal(i3[:1000], items[:1000])
+
+
+def test_float_timestamps_keep_their_order():
+    """fractional float timestamps must not be truncated -- host and device builders sort the same
+    order-preserving int64 keys (IEEE total-order map), so fit and predict see one event order."""
+    ts = np.array([-2.5, -1.0, -0.0, 0.0, 1e-300, 0.25, 0.5, 1.0, 3.25, -1e300, 1e300, 7.75, 7.5])
+    k = D.timestamp_key(ts)
+    assert k.dtype == np.int64
+    assert np.array_equal(np.argsort(k, kind="stable"), np.argsort(ts, kind="stable"))
+    assert k[2] == k[3]                                   # -0.0 and +0.0 tie (the tie then falls to item_idx)
+    assert np.array_equal(D.timestamp_key(torch.tensor(ts)).numpy(), k)
+    ts32 = ts[np.abs(ts) < 1e30].astype(np.float32)
+    assert np.array_equal(D.timestamp_key(ts32), D.timestamp_key(ts32.astype(np.float64)))
+    with pytest.raises(ValueError, match="NaN"):
+        D.timestamp_key(np.array([0.5, np.nan]))
+    # three events of one user within the same second: truncation to int64 would reorder them by item_idx
+    off, items, rew = D.build_csr([0, 0, 0], [9, 5, 7], [10.75, 10.5, 10.25], [1.0, 2.0, 3.0], 1)
+    assert items.tolist() == [7, 5, 9] and rew.tolist() == [3.0, 2.0, 1.0]
+    rng = np.random.default_rng(3)
+    u, i = rng.integers(0, 40, 3000), rng.integers(0, 50, 3000)
+    t = np.round(rng.standard_normal(3000) * 3, 1)          # many ties, negatives, fractions
+    r = rng.integers(1, 6, 3000) / 5.0
+    for x, y in zip(D.build_csr(u, i, t, r, 40), O.build_csr(u, i, t, r, 40)):
+        assert np.array_equal(x, y)
+
+
+def test_arrow_ingest_and_egress_on_cpu():
+    """f1 plumbing without a GPU: Arrow batches -> columns of the hot path's dtypes, REC_SCHEMA egress."""
+    pa = pytest.importorskip("pyarrow")
+    from replay_cql_amd import arrow_io as A
+    ts = pd.to_datetime(["2020-01-03", "2020-01-01", "2020-01-02", "2020-01-05"])
+    t1 = pa.table({"user_idx": pa.array([1, 0, 1, 2], pa.int64()), "item_idx": pa.array([3, 2, 1, 0], pa.int32()),
+                   "timestamp": pa.array(ts.to_numpy().astype("datetime64[us]")), "relevance": pa.array([1, 2, 3, 4], pa.int32())})
+    batches = t1.to_batches(max_chunksize=3)
+    assert len(batches) == 2
+    c = A.columns_to_device(batches, "cpu")
+    assert c["user_idx"].dtype == torch.int32 and c["user_idx"].tolist() == [1, 0, 1, 2]
+    assert c["relevance"].dtype == torch.float64 and c["relevance"].tolist() == [1.0, 2.0, 3.0, 4.0]
+    assert c["timestamp"].dtype == torch.int64
+    assert np.array_equal(np.argsort(c["timestamp"].numpy()), np.argsort(ts.to_numpy()))
+    # same columns as the pandas frame gives (LOG_SCHEMA: replay/constants.py:16-23)
+    assert A.LOG_SCHEMA.names == ["user_idx", "item_idx", "timestamp", "relevance"]
+    only_ids = A.columns_to_device(t1.select(["user_idx", "item_idx"]), "cpu")
+    assert only_ids["timestamp"] is None and only_ids["relevance"] is None
+    with pytest.raises(ValueError, match="nulls"):
+        A.columns_to_device(pa.table({"user_idx": pa.array([1, None], pa.int32()), "item_idx": pa.array([1, 2], pa.int32())}), "cpu")
+    with pytest.raises(Exception):                       # int64 id that does not fit IntegerType
+        A.columns_to_device(pa.table({"user_idx": pa.array([2**40]), "item_idx": pa.array([1])}), "cpu")
+    with pytest.raises(ValueError, match="no column"):
+        A.columns_to_device(pa.table({"user_idx": pa.array([1], pa.int32())}), "cpu")
+    assert A.ids_to_device([5, 3, 5, 1], "user_idx", "cpu").tolist() == [1, 3, 5]
+    assert A.ids_to_device(t1, "user_idx", "cpu").tolist() == [0, 1, 2]
+    # egress: [n x k] block + counts -> exactly the valid prefix of every row, REC_SCHEMA
+    users = torch.tensor([4, 7], dtype=torch.int32)
+    idx = torch.tensor([[9, 8, -1], [1, 2, 3]], dtype=torch.int32)
+    val = torch.tensor([[0.5, 0.25, float("-inf")], [3.0, 2.0, 1.0]])
+    rb = A.recs_to_arrow(users, idx, val, torch.tensor([2, 3], dtype=torch.int32))
+    assert rb.schema.equals(A.REC_SCHEMA)
+    assert rb.to_pydict() == {"user_idx": [4, 4, 7, 7, 7], "item_idx": [9, 8, 1, 2, 3], "relevance": [0.5, 0.25, 3.0, 2.0, 1.0]}
+    assert A.recs_to_arrow(users[:0], idx[:0], val[:0], torch.zeros(0, dtype=torch.int32)).num_rows == 0

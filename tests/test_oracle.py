@@ -9,7 +9,7 @@ import torch
 from oracle import cql_oracle as O
 
 GOLD = Path(__file__).resolve().parent / "golden"
-CASES = ["tiny_dyadic", "small_random", "small_dyadic", "medium_random"]
+CASES = ["tiny_dyadic", "small_random", "small_dyadic", "medium_random", "survey_medium_random", "survey_medium_dyadic"]
 
 
 def _load(name):
@@ -23,6 +23,15 @@ def _load(name):
 def test_oracle_reproduces_golden(name):
     z, (U, Nn, d, L, B, steps, dyadic), (off, items, rew) = _load(name)
     m = O.OracleModel.create(Nn, d, seed=7, dyadic=dyadic)
+    assert np.array_equal(m.theta[:: max(1, m.layout.total // 257)][:257], z["theta0_probe"])
+    # top-K of the initial parameters: on dyadic parameters ids, order and scores are exact (P2)
+    nu0 = min(U, 256)
+    idx0, val0, cnt0, _ = O.predict_topk(m.layout, m.theta, off, items, np.arange(nu0), min(10, Nn), L, filter_seen=True)
+    assert np.array_equal(cnt0, z["topk0_cnt"])
+    if dyadic:
+        assert np.array_equal(idx0, z["topk0_idx"]) and np.array_equal(val0, z["topk0_val"])
+    else:
+        np.testing.assert_allclose(val0, z["topk0_val"], rtol=1e-5, atol=1e-6)
     pos = O.sample_positions(11, 0, 0, B, int(off[-1]))
     users, tpos = O.positions_to_transitions(pos, off)
     assert np.array_equal(users, z["users"]) and np.array_equal(tpos, z["tpos"])
@@ -40,8 +49,6 @@ def test_oracle_reproduces_golden(name):
     np.testing.assert_allclose(m.theta[:: max(1, m.layout.total // 257)][:257], z["theta_probe"], rtol=1e-4, atol=1e-6)
     idx, val, cnt, _ = O.predict_topk(m.layout, m.theta, off, items, np.arange(U), min(10, Nn), L, filter_seen=True)
     assert np.array_equal(cnt, z["topk_cnt"])
-    if dyadic and steps == 0:
-        assert np.array_equal(idx, z["topk_idx"])
     np.testing.assert_allclose(val, z["topk_val"], rtol=1e-4, atol=1e-5)
 
 
