@@ -776,7 +776,9 @@ extern "C" int64_t cqlrec_qhead_bwd_ws_bytes(int64_t batch, int64_t n_items, int
   const QSplit s2 = qs_choose_split(batch, n_items, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
   const int64_t a1 = align256((int64_t)s1.nsplit * batch * d * 4);
   const int64_t a2 = align256((int64_t)s2.nsplit * n_items * d * 4) + align256((int64_t)s2.nsplit * n_items * 4);
-  return (a1 > a2 ? a1 : a2) + 256;
+  const int64_t a3 = cql_qde_ws_bytes(batch, n_items, d);
+  const int64_t m = (a1 > a2 ? a1 : a2);
+  return (m > a3 ? m : a3) + 256;
 }
 
 // dH only (owner = states, streamed = items)
@@ -879,8 +881,16 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
 #undef RED_DE
     }
   };
-  const int64_t rblks_all = (n_items + 127) / 128;
-  launch_range(item_lo, item_hi - item_lo, rblks_all >= QS_TARGET_BLOCKS_BWD);
+  // default: the persistent, statically balanced kernel of qhead_de.hip; CQL_QDE=0 selects the generic skeleton (A/B)
+  static const bool use_qde = !(getenv("CQL_QDE") && getenv("CQL_QDE")[0] == '0');
+  if (use_qde) {
+    const int rc = cql_qde_launch(H_b, nlse2, batch, E_out_b + item_lo * d, b_out + item_lo, item_hi - item_lo, d, scale,
+                                  ws, ws_bytes, g_E_out + item_lo * d, g_b_out + item_lo, sparse_first ? 1 : 0, s);
+    if (rc != CQLREC_OK) return rc;
+  } else {
+    const int64_t rblks_all = (n_items + 127) / 128;
+    launch_range(item_lo, item_hi - item_lo, rblks_all >= QS_TARGET_BLOCKS_BWD);
+  }
   if (!sparse_first && do_sparse) launch_sparse();
   CQL_LAUNCH_CHECK("qhead_bwd_items");
   return CQLREC_OK;
