@@ -343,12 +343,12 @@ static int de_waves(int d) {
   return (d == 256 || w != 8) ? 4 : 8;
 }
 // form 2 (64 items per wave, one wave per SIMD, in-wave pipeline: qhead_de2.hip) for d = 128 unless CQL_QDE2=0
-static bool de_form2(int d) {
+static bool de_form2(int d, int64_t batch) {
   static const int on = de_env_int("CQL_QDE2", 1);
-  return on != 0 && d == 128;
+  return on != 0 && d == 128 && batch % 64 == 0;
 }
 static int de_grid(int64_t n_items, int64_t batch, int d) {
-  const int ti = (d == 256) ? 32 : 64, items = de_form2(d) ? 256 : 32 * de_waves(d);
+  const int ti = (d == 256) ? 32 : 64, items = de_form2(d, batch) ? 256 : 32 * de_waves(d);
   const int64_t G = (n_items + items - 1) / items, T = (batch + ti - 1) / ti;
   static const int per_cu = de_env_int("CQL_QDE_BLOCKS_PER_CU", 0);
   static const int n_cu = [] {
@@ -358,7 +358,7 @@ static int de_grid(int64_t n_items, int64_t batch, int d) {
       n = 256;
     return n;
   }();
-  int64_t slots = (int64_t)n_cu * (per_cu > 0 && !de_form2(d) ? per_cu : (d == 256 || de_form2(d) || de_waves(d) == 8 ? 1 : 2));
+  int64_t slots = (int64_t)n_cu * (per_cu > 0 && !de_form2(d, batch) ? per_cu : (d == 256 || de_form2(d, batch) || de_waves(d) == 8 ? 1 : 2));
   const int64_t W = G * T;
   return (int)(W < slots ? W : slots);
 }
@@ -400,7 +400,7 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
                    int accumulate, hipStream_t s) {
   CQL_REQUIRE(ws_bytes >= cql_qde_ws_bytes(batch, n_items, d), "qde: workspace too small");
   CQL_REQUIRE(batch * 2 * d < (1ll << 31), "qde: batch=%lld too large for one buffer descriptor", (long long)batch);
-  const bool form2 = de_form2(d);
+  const bool form2 = de_form2(d, batch);
   const int ti = (d == 256) ? 32 : 64, waves = form2 ? 8 : de_waves(d), items = form2 ? 256 : 32 * waves;
   QDeArgs a = {};
   a.H_b = H_b;

@@ -157,233 +157,205 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
     }
   };
 
-  // ---- the pieces of a tile -----------------------------------------------------------------------------------------------
-  bf16x8 af[KS];      // row fragments of the tile whose S chains run next (read one slot 4 ahead)
-  f32x16 sv;          // -lse of that tile's states = C operand of its S chains
-  auto read_rows = [&](auto NEXT, auto IT) {        // 8 + 4 ds_read_b128; NEXT: from the other ring buffer
-    constexpr int toff = decltype(IT)::value * C::TILE_BYTES;
-    const lds_u8* b0 = decltype(NEXT)::value ? nA0 : pA0;
-    const lds_u8* b1 = decltype(NEXT)::value ? nA1 : pA1;
-    const lds_u8* bs = decltype(NEXT)::value ? nS : pS;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) af[s] = *(const lds_bf16x8*)(((s & 1) ? b1 : b0) + toff + 512 * (s >> 1));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 t4 = *(const lds_f4*)(bs + 128 * decltype(IT)::value + 32 * q);
-      sv[4 * q + 0] = t4[0];
-      sv[4 * q + 1] = t4[1];
-      sv[4 * q + 2] = t4[2];
-      sv[4 * q + 3] = t4[3];
-    }
-  };
-  // One tile = four slots of 8 MFMAs, written in the order they are meant to ISSUE: every MFMA is followed by its share of
-  // the other pipes' work, and __builtin_amdgcn_sched_barrier(0) after each piece keeps hipcc's scheduler from regrouping
-  // them (left alone it issues the chains back to back and the exponentials in one lump behind them).
-  //   exponentials of a group, in 8 chunks of two elements: 2 fma, 2 exp2, 2 adds (column sum), 1 bf16 pack = word k of
-  //   the B operand of the second chain (k-order = accumulator row order).
+  // ---- the software pipeline ---------------------------------------------------------------------------------------
+  // Per tile (32 states x this wave's 2 x 32 items): four MFMA chains of 8 -- A = S0, B = S1 (scores of the two item
+  // groups), C = dE0, D = dE1 (their gradient products) -- and 32 "half-chunks" of VALU work (P0 then P1: 2 fma + exp /
+  // exp + 2 add + pack for two probabilities).  Measured on this chip (tools/probes/mfma_probe.hip, one wave per SIMD): an
+  // MFMA followed by a half-chunk issues every 34 cycles, a whole 7-instruction chunk behind one MFMA makes the gap 46
+  // cycles, one ds_read_b128 per gap adds ~5.  So ONE half-chunk per MFMA, all 32 gaps of a tile used, and the chains of
+  // THREE tiles in flight -- the "period" of tile t:
+  //
+  //   gap     MFMA                          VALU              LDS (one read per gap, into the OTHER register set)
+  //   0-4     D(t-1), last 5                P0(t)  0-4        gap 4: [ring turn if t ends a stage]
+  //   5-12    B(t)   (rows of t, read in    P0(t)  5-12       gaps 4-15: strip + rows of tile t+1
+  //                   period t-1)
+  //   13-20   C(t)                          P0 13-15, P1 0-4
+  //   21-28   A(t+1)                        P1(t)  5-12       gaps 16-31: transposed reads of tile t+1
+  //   29-31   D(t), first 3                 P1(t) 13-15
+  //
+  // A(t) was done in period t-1; P0 reads its accumulator from gap 0 on (the chain ended 3 gaps earlier), P1 reads B's
+  // from gap 16 (3 gaps behind it); C's first four products need words 0-3 of P0 (gap 7), the others words 4-7 (gap 15);
+  // D's first four need words 0-3 of P1 (gap 23), its others words 4-7 (gap 31) -- they run in gaps 0-4 of the next period.
+  // A group (or the block's range) ends: the period runs without A(t+1), the 5 products of D drain behind it.
 #define QDE2_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // exponentials of a group in 8 chunks of two elements: 2 fma, 2 exp2, 2 adds (column sum), 1 bf16 pack = word k of the
-  // B operand of the second chain (k-order = accumulator row order).  ONE volatile asm statement per chunk: hipcc otherwise
-  // sinks the adds to the end of the stage (and packs them into v_pk_add_f32), keeping all 32 exponentials of a tile alive,
-  // and lowers the pack of two separately converted values to 4 instructions.  Hazards inside: the two v_exp results are read
-  // one instruction later at the earliest (gfx950: one wait state behind a transcendental); the accumulator registers read
-  // here were written by an MFMA chain that ended at least three MFMAs earlier (slot layout below).
-  auto chunk = [&](const f32x16& acc, int gi, int k, uint32_t (&pw)[8], float& csum, int64_t left) {
-    float t0, t1;
-    uint32_t w;
-#if defined(QDE2_ABL_NOCHUNK)      // timing-only build: one pack instead of the 7-instruction chunk
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=&v"(w) : "v"(acc[2 * k]), "v"(acc[2 * k + 1]));
-    t0 = t1 = 0.f;
-    (void)csum; (void)left;
-    pw[k] = w;
+  bf16x8 af[2][KS];         // row fragments, by tile parity inside the stage (those of tile t+1 are read while B(t) and
+  f32x16 sv[2];             // C(t) still run on tile t's); -lse of the tile's states = C operand of its S chains
+  f32x16 acc0, acc1;        // S accumulators: A writes acc0, B writes acc1
+  bf16x8 tf[2][FT][2];      // transposed fragments, by tile parity inside the stage
+  bf16x8 dpa, dpb;          // P1 fragments of the previous tile (for the D products still pending)
+  float ht0 = 0.f, ht1 = 0.f;      // the two exponent arguments / values travelling from half A to half B of a chunk
+  // half-chunks of the exponentials.  Volatile asm: hipcc would otherwise regroup them (sinks the column sums to the end
+  // of the stage as v_pk_add_f32 and keeps every exponential alive).  Half B reads a v_exp result one instruction later
+  // at the earliest (gfx950: one wait state behind a transcendental).
+  auto half_a = [&](const f32x16& acc, int k, float b0, float b1) {
+#ifdef QDE2_ABL_NOCHUNK      // timing-only build: no exponentials
+    ht0 = acc[2 * k]; ht1 = acc[2 * k + 1];
     return;
-#elif defined(QDE2_ABL_NOEXP)      // timing-only build: the transcendentals become moves
+#endif
     asm volatile(
-        "v_fmamk_f32 %0, %4, 0x3fb8aa3b, %6\n\t"
-        "v_fmamk_f32 %1, %5, 0x3fb8aa3b, %6\n\t"
-        "v_mov_b32 %0, %0\n\t"
-        "v_mov_b32 %1, %1\n\t"
+        "v_fmamk_f32 %0, %2, 0x3fb8aa3b, %4\n\t"
+        "v_fmamk_f32 %1, %3, 0x3fb8aa3b, %5\n\t"
+        "v_exp_f32 %0, %0"
+        : "=&v"(ht0), "=&v"(ht1)
+        : "v"(acc[2 * k]), "v"(acc[2 * k + 1]), "v"(b0), "v"(b1));
+  };
+  auto half_b = [&](uint32_t& w, float& csum) {
+#ifdef QDE2_ABL_NOCHUNK
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=&v"(w) : "v"(ht0), "v"(ht1));
+    return;
+#endif
+    asm volatile(
+        "v_exp_f32 %1, %1\n\t"
         "v_add_f32 %3, %3, %0\n\t"
         "v_add_f32 %3, %3, %1\n\t"
         "v_cvt_pk_bf16_f32 %2, %0, %1"
-        : "=&v"(t0), "=&v"(t1), "=&v"(w), "+v"(csum)
-        : "v"(acc[2 * k]), "v"(acc[2 * k + 1]), "v"(bl2[gi]));
-    (void)left;
-    pw[k] = w;
-    return;
-#endif
-    if constexpr (!MASK) {
-      asm volatile(
-          "v_fmamk_f32 %0, %4, 0x3fb8aa3b, %6\n\t"
-          "v_fmamk_f32 %1, %5, 0x3fb8aa3b, %6\n\t"
-          "v_exp_f32 %0, %0\n\t"
-          "v_exp_f32 %1, %1\n\t"
-          "v_add_f32 %3, %3, %0\n\t"
-          "v_add_f32 %3, %3, %1\n\t"
-          "v_cvt_pk_bf16_f32 %2, %0, %1"
-          : "=&v"(t0), "=&v"(t1), "=&v"(w), "+v"(csum)
-          : "v"(acc[2 * k]), "v"(acc[2 * k + 1]), "v"(bl2[gi]));
-    } else {      // states past the end of the batch contribute nothing: exp2(-inf) = 0
-      const float m0 = (mfma_row(2 * k, h) < left) ? bl2[gi] : NEG_INF_F;
-      const float m1 = (mfma_row(2 * k + 1, h) < left) ? bl2[gi] : NEG_INF_F;
-      asm volatile(
-          "v_fmamk_f32 %0, %4, 0x3fb8aa3b, %6\n\t"
-          "v_fmamk_f32 %1, %5, 0x3fb8aa3b, %7\n\t"
-          "v_exp_f32 %0, %0\n\t"
-          "v_exp_f32 %1, %1\n\t"
-          "v_add_f32 %3, %3, %0\n\t"
-          "v_add_f32 %3, %3, %1\n\t"
-          "v_cvt_pk_bf16_f32 %2, %0, %1"
-          : "=&v"(t0), "=&v"(t1), "=&v"(w), "+v"(csum)
-          : "v"(acc[2 * k]), "v"(acc[2 * k + 1]), "v"(m0), "v"(m1));
-    }
-    pw[k] = w;
+        : "+v"(ht0), "+v"(ht1), "=&v"(w), "+v"(csum));
   };
   auto frag = [](const uint32_t (&pw)[8], int s2) {
     u32x4 v = {pw[4 * s2 + 0], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
     return __builtin_bit_cast(bf16x8, v);
   };
-  // One tile = four slots of 8 MFMAs (d = 128), written in the order they are meant to ISSUE; a fence after each piece keeps
-  // hipcc's scheduler from regrouping them (left alone it issues the chains back to back and the exponentials in one lump).
-  //   slot 1   S0 chain, 2 transposed reads of this tile behind each MFMA
-  //   slot 2   S1 chain; from its 4th MFMA on one chunk of P0 behind each MFMA (5 chunks)
-  //   slot 3   dE0 chain (the s2 = 0 products first: they need words 0..3); chunks 5..7 of P0 behind its first three
-  //            MFMAs, chunks 0..4 of P1 behind the others
-  //   slot 4   dE1 chain; chunks 5..7 of P1 behind its first three MFMAs; [end of a stage: the ring turns]; the 12 row
-  //            reads of the next tile behind the others
-  // `more`: another stage follows in this block's range; END: last tile of its stage (`cur_buf` = the ring buffer this
-  // stage lives in, refilled with stage + 2).
-  static_assert(KS == 8, "slot layout written for d = 128");
-  constexpr int LAG = 3;      // MFMAs between the end of an S chain and the first read of its accumulator
-  auto tile = [&](auto IT, auto END, bool more, bool refill, int cur_buf) {
-    constexpr int toff = decltype(IT)::value * C::TILE_BYTES;
-    const int64_t left = MASK ? (a.n_states - ((int64_t)t * C::TI + 32 * decltype(IT)::value)) : 32;
-    f32x16 acc0 = sv, acc1 = sv;
-    bf16x8 tf[FT][2];
-    uint32_t pw0[8], pw1[8];
-    float c0 = 0.f, c1 = 0.f;
-    // ---- slot 1
-    constexpr int TRP = (4 * FT) / KS;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], rf[0][s], acc0, 0, 0, 0);
-      QDE2_FENCE();
-#pragma unroll
-      for (int e = 0; e < TRP; ++e) {
-        const int idx = s * TRP + e, ft = idx >> 2, s2 = (idx >> 1) & 1, jj = idx & 1;
-#ifdef QDE2_ABL_NOTR       // timing-only build: no transposed reads
-        bf16x4 t4 = {af[s][0], af[s][1], af[s][2], af[s][3]};
-        asm volatile("" : "+v"(t4));
-#else
-        const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (lds_bf16x4*)((jj ? pT1 : pT0) + toff + C::RG_BYTES * (2 * s2 + jj) + 512 * ft));
+  // LDS reads of the tile FOLLOWING tile (cur buffer, IT): NIT = its index in its stage, from the other buffer if IT is
+  // the last tile of the stage.  idx 0..3 strip, 4..11 rows, 12..27 transposed.
+  auto next_read = [&](auto IT, int idx) {
+#if defined(QDE2_ABL_NOROWS) && defined(QDE2_ABL_NOTR)      // timing-only build: no LDS reads in the loop
+    if (t >= 0) return;
+#elif defined(QDE2_ABL_NOROWS)
+    if (idx < 4 + KS) return;
+#elif defined(QDE2_ABL_NOTR)
+    if (idx >= 4 + KS) return;
 #endif
-        tf[ft][s2][4 * jj + 0] = t4[0];
-        tf[ft][s2][4 * jj + 1] = t4[1];
-        tf[ft][s2][4 * jj + 2] = t4[2];
-        tf[ft][s2][4 * jj + 3] = t4[3];
-      }
-      QDE2_FENCE();
-    }
-    // ---- slot 2 (every index below is a compile-time constant after unrolling: a counter carried through the loops
-    // would leave the arrays runtime-indexed when SROA runs, i.e. in scratch memory)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], rf[1][s], acc1, 0, 0, 0);
-      QDE2_FENCE();
-      if (s >= LAG) {
-        chunk(acc0, 0, s - LAG, pw0, c0, left);                 // chunks 0 .. 4
-        QDE2_FENCE();
-      }
-    }
-    // ---- the ring turns here at the end of a stage: the transposed reads of this tile (slot 1) are back by now, the row
-    // reads of the next tile -- from the other buffer -- start right behind it, a slot and a half before their S chains
-    // (the reads are issued unconditionally: behind the block's last stage they fetch stale LDS bytes nobody uses -- a
-    // run-time branch around them would duplicate the MFMA chains and make hipcc shuffle the accumulators at the join)
-    constexpr int NIT = decltype(END)::value ? 0 : 1;
+    constexpr bool END = decltype(IT)::value == C::TILES - 1;
+    constexpr int NIT = END ? 0 : decltype(IT)::value + 1;
     constexpr int noff = NIT * C::TILE_BYTES;
-    const lds_u8* b0 = decltype(END)::value ? nA0 : pA0;
-    const lds_u8* b1 = decltype(END)::value ? nA1 : pA1;
-    const lds_u8* bs = decltype(END)::value ? nS : pS;
-    if constexpr (decltype(END)::value) {
-      if (more) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): nobody still reads the buffer that is refilled below
-        de_wait_vmcnt<0>();                       // this wave's pieces of the next stage have landed
+    if (idx < 4) {
+      const f32x4 t4 = *(const lds_f4*)((END ? nS : pS) + 128 * NIT + 32 * idx);
+      sv[NIT & 1][4 * idx + 0] = t4[0];
+      sv[NIT & 1][4 * idx + 1] = t4[1];
+      sv[NIT & 1][4 * idx + 2] = t4[2];
+      sv[NIT & 1][4 * idx + 3] = t4[3];
+    } else if (idx < 4 + KS) {
+      const int sa = idx - 4;
+      af[NIT & 1][sa] = *(const lds_bf16x8*)(((sa & 1) ? (END ? nA1 : pA1) : (END ? nA0 : pA0)) + noff + 512 * (sa >> 1));
+    } else {
+      const int q = idx - 4 - KS, ft = q >> 2, s2 = (q >> 1) & 1, jj = q & 1;
+      const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (lds_bf16x4*)((jj ? (END ? nT1 : pT1) : (END ? nT0 : pT0)) + noff + C::RG_BYTES * (2 * s2 + jj) + 512 * ft));
+      tf[NIT & 1][ft][s2][4 * jj + 0] = t4[0];
+      tf[NIT & 1][ft][s2][4 * jj + 1] = t4[1];
+      tf[NIT & 1][ft][s2][4 * jj + 2] = t4[2];
+      tf[NIT & 1][ft][s2][4 * jj + 3] = t4[3];
+    }
+  };
+  // the ring turns (tile = last of its stage): the next stage's pieces have landed for everyone, everyone has left this
+  // stage's buffer (its last reads were issued in the previous period), which is refilled with stage + 2
+  auto ring_turn = [&](bool more, bool refill, int cur_buf) {
+    if (more) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of the buffer refilled below (issued >= 4 gaps ago)
+      de_wait_vmcnt<0>();
 #ifndef QDE_ABL_NOBAR
-        __builtin_amdgcn_s_barrier();             // everyone's have; everyone left this stage's buffer
+      __builtin_amdgcn_s_barrier();
 #endif
 #ifdef QDE_ABL_NODMA
-        if (false) {
+      if (false) {
 #else
-        if (refill) {
+      if (refill) {
 #endif
-          issue(t_dma, cur_buf);
-          if (++t_dma == a.T) t_dma = 0;
-        }
-      }
-    }
-    // read `idx` of the next tile: 0..3 strip (the C operand of its S chains), 4..11 row fragments
-    auto next_read = [&](int idx) {
-#ifndef QDE2_ABL_NOROWS
-      if (idx < 4) {
-        const f32x4 t4 = *(const lds_f4*)(bs + 128 * NIT + 32 * idx);
-        sv[4 * idx + 0] = t4[0];
-        sv[4 * idx + 1] = t4[1];
-        sv[4 * idx + 2] = t4[2];
-        sv[4 * idx + 3] = t4[3];
-      } else {
-        const int sa = idx - 4;
-        af[sa] = *(const lds_bf16x8*)(((sa & 1) ? b1 : b0) + noff + 512 * (sa >> 1));
-      }
-#endif
-    };
-    // ---- slot 3
-    bf16x8 pa0 = {}, pb0 = {};
-    {
-#pragma unroll
-      for (int m = 0; m < 2 * FT; ++m) {
-        const int ft = m % FT, s2 = m / FT;
-        if (m == 0) pa0 = frag(pw0, 0);
-        if (m == FT) pb0 = frag(pw0, 1);
-        y[0][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ft][s2], s2 ? pb0 : pa0, y[0][ft], 0, 0, 0);
-        QDE2_FENCE();
-        if (m < LAG) chunk(acc0, 0, KS - LAG + m, pw0, c0, left);   // chunks 5 .. 7 of P0
-        else chunk(acc1, 1, m - LAG, pw1, c1, left);                // chunks 0 .. 4 of P1
-        QDE2_FENCE();
-        next_read(m);                                               // one read behind each MFMA: strip, rows 0 .. 3
-        QDE2_FENCE();
-      }
-    }
-    cs[0] += c0;
-    // ---- slot 4
-    bf16x8 pa1 = {}, pb1 = {};
-    auto de1 = [&](int m) {
-      const int ft = m % FT, s2 = m / FT;
-      y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ft][s2], s2 ? pb1 : pa1, y[1][ft], 0, 0, 0);
-      QDE2_FENCE();
-    };
-    pa1 = frag(pw1, 0);
-#pragma unroll
-    for (int m = 0; m < LAG; ++m) {
-      de1(m);
-      chunk(acc1, 1, KS - LAG + m, pw1, c1, left);              // chunks 5 .. 7 of P1
-      QDE2_FENCE();
-    }
-    cs[1] += c1;
-    pb1 = frag(pw1, 1);
-#pragma unroll
-    for (int m = LAG; m < 2 * FT; ++m) {
-      de1(m);
-      if (2 * FT + (m - LAG) < KS + 4) {
-        next_read(2 * FT + (m - LAG));                             // rows 4 .. 7
-        QDE2_FENCE();
+        issue(t_dma, cur_buf);
+        if (++t_dma == a.T) t_dma = 0;
       }
     }
   };
+  // A chain of the tile whose rows are in af / sv, on its own (first tile of a group)
+  auto chain_a_alone = [&]() {      // (a piece starts with the first tile of a stage: parity 0)
+    acc0 = sv[0];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s], rf[0][s], acc0, 0, 0, 0);
+  };
+  // the last 5 products of D of tile (parity IT), on their own (last tile of a group)
+  auto drain_d = [&](auto IT) {
+    constexpr int P = decltype(IT)::value & 1;
+#pragma unroll
+    for (int m = 3; m < 2 * FT; ++m) {
+      const int ft = m % FT, s2 = m / FT;
+      y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P][ft][s2], s2 ? dpb : dpa, y[1][ft], 0, 0, 0);
+    }
+  };
+  // one period.  There is ONE form per tile parity: at the first tile of a piece the pending D products run on zeroed
+  // P fragments (they add nothing), at its last tile the A chain of the following tile is computed in vain (the next
+  // piece redoes it with its own owner fragments) -- run-time variants of the period would duplicate the chains under a
+  // branch, and hipcc then shuffles the accumulators at every join.
+  auto period = [&](auto IT, bool more, bool refill, int cur_buf) {
+    constexpr int P = decltype(IT)::value & 1;                 // register set of this tile's transposed fragments
+    constexpr bool END = decltype(IT)::value == C::TILES - 1;
+    const int64_t left = MASK ? (a.n_states - ((int64_t)t * C::TI + 32 * decltype(IT)::value)) : 32;
+    uint32_t pw0[8], pw1[8];
+    float c0 = 0.f, c1 = 0.f;
+    bf16x8 pa0 = {}, pb0 = {}, pa1 = {};
+    auto bias_of = [&](int gi, int elem) {       // exponent addend of accumulator element `elem`; -inf past the batch's end
+      if constexpr (MASK) return (mfma_row(elem, h) < left) ? bl2[gi] : NEG_INF_F;
+      else return bl2[gi];
+    };
+#pragma unroll
+    for (int gp = 0; gp < 32; ++gp) {
+      // ---- MFMA of this gap
+      if (gp < 5) {
+        const int m = 3 + gp, ft = m % FT, s2 = m / FT;
+        y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P ^ 1][ft][s2], s2 ? dpb : dpa, y[1][ft], 0, 0, 0);
+      } else if (gp < 13) {
+        const int s = gp - 5;
+        if (s == 0) acc1 = sv[P];
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P][s], rf[1][s], acc1, 0, 0, 0);
+      } else if (gp < 21) {
+        const int m = gp - 13, ft = m % FT, s2 = m / FT;
+        if (m == 0) pa0 = frag(pw0, 0);
+        if (m == FT) pb0 = frag(pw0, 1);
+        y[0][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P][ft][s2], s2 ? pb0 : pa0, y[0][ft], 0, 0, 0);
+      } else if (gp < 29) {
+        const int s = gp - 21;
+        if (s == 0) acc0 = sv[P ^ 1];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P ^ 1][s], rf[0][s], acc0, 0, 0, 0);
+      } else {
+        const int m = gp - 29, ft = m % FT;
+        if (m == 0) pa1 = frag(pw1, 0);
+        y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P][ft][0], pa1, y[1][ft], 0, 0, 0);
+      }
+      QDE2_FENCE();
+      // ---- half-chunk of this gap: P0 in gaps 0-15 (from acc0), P1 in gaps 16-31 (from acc1)
+      {
+        const int hc = gp & 15, k = hc >> 1;
+        if (gp < 16) {
+          if ((hc & 1) == 0) half_a(acc0, k, bias_of(0, 2 * k), bias_of(0, 2 * k + 1));
+          else half_b(pw0[k], c0);
+        } else {
+          if ((hc & 1) == 0) half_a(acc1, k, bias_of(1, 2 * k), bias_of(1, 2 * k + 1));
+          else half_b(pw1[k], c1);
+        }
+      }
+      QDE2_FENCE();
+      // ---- LDS reads of the next tile, one per gap: strip + rows in gaps 4-15 (second register set: B(t) and A(t+1)
+      // run on different sets), transposed fragments in gaps 16-31.  The ring turns in front of the first of them.
+      if (gp == 4) {
+        if constexpr (END) ring_turn(more, refill, cur_buf);
+      }
+      if (gp >= 4) next_read(IT, gp - 4);
+      QDE2_FENCE();
+    }
+    cs[0] += c0;
+    cs[1] += c1;
+    dpa = pa1;
+    dpb = frag(pw1, 1);
+  };
 
   load_owner(g);
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) tf[pp][ft][s2] = bf16x8{};     // finite: the first tile's pending-D products add 0 * this
 
-  // ---- prologue of the ring: stages 0 and 1 in flight, rows of the first tile in registers ---------------------------
+  // ---- prologue: stages 0 and 1 in flight; rows, strip and transposed fragments of the first tile in registers ----
   int issued = 0;
   for (int s0 = 0; s0 < 2 && s0 < nst; ++s0) {
     issue(t_dma, s0);
@@ -392,20 +364,34 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
   }
   de_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
-  using I0 = std::integral_constant<int, 0>;
-  using BT = std::integral_constant<bool, true>;
-  using BF = std::integral_constant<bool, false>;
-  read_rows(BF{}, I0{});
+  {   // "the tile following tile -1": read through next_read with the roles of the buffers swapped
+    { const lds_u8* x = pA0; pA0 = nA0; nA0 = x; }
+    { const lds_u8* x = pA1; pA1 = nA1; nA1 = x; }
+    { const lds_u8* x = pT0; pT0 = nT0; nT0 = x; }
+    { const lds_u8* x = pT1; pT1 = nT1; nT1 = x; }
+    { const lds_u8* x = pS; pS = nS; nS = x; }
+#pragma unroll
+    for (int idx = 0; idx < 4 + KS + 4 * FT; ++idx) next_read(std::integral_constant<int, C::TILES - 1>{}, idx);
+    { const lds_u8* x = pA0; pA0 = nA0; nA0 = x; }
+    { const lds_u8* x = pA1; pA1 = nA1; nA1 = x; }
+    { const lds_u8* x = pT0; pT0 = nT0; nT0 = x; }
+    { const lds_u8* x = pT1; pT1 = nT1; nT1 = x; }
+    { const lds_u8* x = pS; pS = nS; nS = x; }
+  }
 
   // pieces of item groups (outer) x stages of the piece (inner): the owner fragments are invariant in the inner loop
   int j = 0, cur_buf = 0;
   while (j < nst) {
     int seg_end = j + (a.T - t);
     if (seg_end > nst) seg_end = nst;
+    chain_a_alone();                      // A of the piece's first tile (its rows are in registers)
+    dpa = bf16x8{};                       // nothing pending from a previous tile of this group
+    dpb = bf16x8{};
     for (; j < seg_end; ++j) {
       const bool more = j + 1 < nst, refill = issued < nst;
-      if constexpr (C::TILES == 2) tile(I0{}, BF{}, true, false, cur_buf);
-      tile(std::integral_constant<int, C::TILES - 1>{}, BT{}, more, refill, cur_buf);
+      static_assert(C::TILES == 2, "two tiles per stage");
+      period(std::integral_constant<int, 0>{}, true, false, cur_buf);
+      period(std::integral_constant<int, 1>{}, more, refill, cur_buf);
       if (more && refill) ++issued;
       ++t;
       // the ring turned: the other buffer is the current one now
@@ -416,6 +402,7 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
       { const lds_u8* x = pS; pS = nS; nS = x; }
       cur_buf ^= 1;
     }
+    drain_d(std::integral_constant<int, 1>{});
     store_piece(g, t_seg == 0);
     if (j < nst) {
       ++g;
@@ -445,8 +432,8 @@ static void qde2_launch_n(const QDeArgs& a, int grid, hipStream_t s) {
 
 // rows [0, n_items): `a` prepared by cql_qde_launch (G, T for 256-item groups; nlse2 = -lse in NATURAL units here)
 int cql_qde2_run(const QDeArgs& a, int d, int grid, hipStream_t s) {
-  const bool mask = (a.n_states % DeCfg<128, 4>::TI) != 0;
-  if (d == 128) { if (mask) qde2_launch_n<128, true>(a, grid, s); else qde2_launch_n<128, false>(a, grid, s); }
-  else return CQLREC_ERR_INVALID;
+  // whole stages only (the caller keeps the generic form for batches that are not a multiple of 64 states)
+  if (d != 128 || (a.n_states % DeCfg<128, 4>::TI) != 0) return CQLREC_ERR_INVALID;
+  qde2_launch_n<128, false>(a, grid, s);
   return CQLREC_OK;
 }
