@@ -271,13 +271,13 @@ def main():
         seen_items = items[torch.argsort(rows * NI + items.to(torch.int64))].contiguous()
         del rows
         hb = core.encode(off, items, users)
-        core.score_topk(hb[:1024], K, seen=(off, seen_items))      # warm-up
+        core.score_topk(hb[:1024], K, seen=(off, seen_items), chunk=nu)      # warm-up
         barrier()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
             hb = core.encode(off, items, users)
-            idx, val, cnt = core.score_topk(hb, K, seen=(off, seen_items))
+            idx, val, cnt = core.score_topk(hb, K, seen=(off, seen_items), chunk=nu)
         barrier()
         dtk = time.perf_counter() - t1
         # per-kernel durations from one more, event-bracketed pass (not part of `value`: the brackets cost ~8 % here)
@@ -285,7 +285,7 @@ def main():
         if not args.no_prof:
             N.check(lib.cqlrec_prof_enable(1), "prof_enable")
             hb = core.encode(off, items, users)
-            core.score_topk(hb, K, seen=(off, seen_items))
+            core.score_topk(hb, K, seen=(off, seen_items), chunk=nu)
             barrier()
             tk_ph = N.prof_read()
             N.check(lib.cqlrec_prof_enable(0), "prof_enable")
@@ -296,15 +296,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtk = float(t.item())
         topk = {"metric": "top-K users/sec", "value": world * reps * nu / dtk, "unit": "users/s", "k": K,
-                "users_per_rank": nu, "filter_seen": True, "ms_per_pass": 1e3 * dtk / reps}
+                "users_per_rank": nu, "filter_seen": True, "ms_per_pass": 1e3 * dtk / reps,
+                # the whole pass (encode + seen bitmap + scoring/selection + list merge) against the bf16 MFMA peak
+                "pass_mfma_frac": 2.0 * nu * NI * d / (dtk / reps) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
         if tk_ph.get("topk_tilemax", (0, 0))[1]:
             ms = tk_ph["topk_tilemax"][0] / tk_ph["topk_tilemax"][1]
             launches_per_pass = tk_ph["topk_tilemax"][1] / tk_reps
             fl = 2.0 * nu * NI * d / launches_per_pass
-            topk["roofline"] = {"kernel": "qstream_kernel<TILEMAX>", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+            fused = (d == 128 and K <= 16)
+            topk["roofline"] = {"kernel": "qtopk2_kernel<128> (scores + on-chip top-k selection)" if fused
+                                else "qstream_kernel<TOPK> / <TILEMAX>", "bound": "mfma",
+                                "achieved": fl / (ms * 1e-3) / 1e12,
                                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
-                                "avg_ms": ms}
+                                "avg_ms": ms, "launches_per_pass": launches_per_pass}
             topk["select_ms_per_pass"] = tk_ph["topk_select"][0] / tk_reps
         if tk_ph.get("gather_fwd", (0, 0))[1]:
             # the window gather at a size that fills the chip: one launch over all `nu` users of the scoring pass

@@ -464,7 +464,7 @@ class CQLCore:
 
     def score_topk(self, hb: torch.Tensor, k: int, cand_items: Optional[torch.Tensor] = None,
                    seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
-                   chunk: int = 32768) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                   chunk: int = 65536) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Top-k (score desc, item id asc) for the state vectors hb.  cand_items: ascending int32 global ids (None =
         whole catalog).  seen = (offsets int64, ascending item ids int32) CSR; seen_rows maps hb rows to CSR rows."""
         h, lay = self.hyper, self.layout

@@ -151,6 +151,64 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
     st_b[g] = 0.f;          // running sum (LSE) / column sum of P (BWD_DE)
     st_i[g] = 0x7FFFFFFF;   // argmax
   }
+  // QM_TOPK: per 32-user group the list of the QS_TOPK_K best admissible candidates of THIS lane's half of every tile
+  // (sorted, best first; 0 = none), the pruning bound (the k-th best admissible score known for the user, shared by
+  // the two lane halves), and a small LDS buffer of candidates that beat the bound since the last merge.
+  constexpr bool TOPK = (MODE == QM_TOPK);
+  unsigned long long tk_lst[TOPK ? SPW : 1][TOPK ? QS_TOPK_K : 1];
+  float tk_thr[TOPK ? SPW : 1];
+  int tk_cnt[TOPK ? SPW : 1];
+  const uint32_t* tk_bits[TOPK ? SPW : 1];
+  unsigned long long* tk_buf = nullptr;      // [SPW][QS_TOPK_BUF][64 lanes] of this wave
+  if constexpr (TOPK) {
+    tk_buf = reinterpret_cast<unsigned long long*>(smem + NBUF * C::BUF_BYTES) + (size_t)wave * SPW * QS_TOPK_BUF * 64;
+#pragma unroll
+    for (int g = 0; g < SPW; ++g) {
+#pragma unroll
+      for (int j = 0; j < QS_TOPK_K; ++j) tk_lst[g][j] = 0ull;
+      tk_thr[g] = -3.0e38f;     // finite: rows past the end of the catalogue score -inf and never qualify
+      tk_cnt[g] = 0;
+      int64_t urow = res0 + g * 32 + r;
+      if (urow >= a.n_res) urow = a.n_res - 1;
+      tk_bits[g] = a.seen_bits ? a.seen_bits + urow * a.seen_w : nullptr;
+    }
+  }
+  // Merge the buffered candidates of group g into its list (whole wave).  Seen items are dropped HERE: only candidates
+  // that beat the bound are ever looked up (about k ln(n / k) per list), one bitmap word each, the loads of a merge in
+  // flight together.  (hipcc waits vmcnt(0) for them, which also drains the prefetch ring -- once per merge.)
+  auto tk_merge = [&](int g) {
+    if constexpr (TOPK) {
+      unsigned long long key[QS_TOPK_BUF];
+      uint32_t wd[QS_TOPK_BUF];
+#pragma unroll
+      for (int e = 0; e < QS_TOPK_BUF; ++e)
+        key[e] = (e < tk_cnt[g]) ? tk_buf[(g * QS_TOPK_BUF + e) * 64 + lane] : 0ull;
+#pragma unroll
+      for (int e = 0; e < QS_TOPK_BUF; ++e) {
+        const uint32_t c = ~(uint32_t)(key[e] & 0xFFFFFFFFull);
+        wd[e] = (key[e] != 0ull && tk_bits[g]) ? tk_bits[g][c >> 5] : 0u;
+      }
+#pragma unroll
+      for (int e = 0; e < QS_TOPK_BUF; ++e) {
+        const uint32_t c = ~(uint32_t)(key[e] & 0xFFFFFFFFull);
+        unsigned long long kx = ((wd[e] >> (c & 31)) & 1u) ? 0ull : key[e];
+#pragma unroll
+        for (int j = 0; j < QS_TOPK_K; ++j) {       // insertion into the sorted list: keys are distinct
+          const bool gt = kx > tk_lst[g][j];
+          const unsigned long long hi_ = gt ? kx : tk_lst[g][j];
+          kx = gt ? tk_lst[g][j] : kx;
+          tk_lst[g][j] = hi_;
+        }
+      }
+      tk_cnt[g] = 0;
+      unsigned long long kk = 0ull;      // k-th entry through a static-index select chain (k is a run-time value)
+#pragma unroll
+      for (int j = 0; j < QS_TOPK_K; ++j) kk = (j == a.topk_k - 1) ? tk_lst[g][j] : kk;
+      const float own = (kk != 0ull) ? f32_from_order_key((uint32_t)(kk >> 32)) : -3.0e38f;
+      // k admissible items of the OTHER half at or above its bound exclude everything below that bound as well
+      tk_thr[g] = fmaxf(own, __shfl_xor(own, 32));
+    }
+  };
   f32x16 y[BWD ? SPW : 1][BWD ? FT : 1];
   if constexpr (BWD) {
 #pragma unroll
@@ -289,6 +347,30 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
           st_a[g] = upd ? tmax : st_a[g];
           st_i[g] = upd ? (int)tile_row0 : st_i[g];
         }
+      } else if constexpr (MODE == QM_TOPK) {
+#pragma unroll
+        for (int g = 0; g < SPW; ++g) {
+          float tmax = acc[g][0];
+#pragma unroll
+          for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[g][i]);
+          // ">=": an item that ties with the k-th best but has a smaller id still belongs in front of it
+          if (__builtin_amdgcn_ballot_w64(tmax >= tk_thr[g]) != 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool c = acc[g][i] >= tk_thr[g];
+              if (__builtin_amdgcn_ballot_w64(c) != 0) {
+                if (__builtin_amdgcn_ballot_w64(c && tk_cnt[g] >= QS_TOPK_BUF) != 0) tk_merge(g);
+                const bool c2 = acc[g][i] >= tk_thr[g];      // the merge may have raised the bound
+                if (c2) {
+                  const uint32_t row = (uint32_t)(tile_row0 + mfma_row(i, h));
+                  tk_buf[(g * QS_TOPK_BUF + tk_cnt[g]) * 64 + lane] =
+                      ((unsigned long long)f32_order_key(acc[g][i]) << 32) | (unsigned long long)(~row);
+                  tk_cnt[g] += 1;
+                }
+              }
+            }
+          }
+        }
       } else if constexpr (MODE == QM_TILEMAX) {
         const int64_t tile_idx = tile_row0 >> 5;
         const bool flush = ((tile_idx + 1) % a.tg == 0) || (tile_row0 + 32 >= s_end);
@@ -408,6 +490,14 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         a.part_a[pidx] = M;
         a.part_b[pidx] = Lsum;
       }
+    } else if constexpr (MODE == QM_TOPK) {
+      tk_merge(g);
+      if (ok) {
+        unsigned long long* dst = a.topk_keys + (((int64_t)split * a.n_res + row) * 2 + h) * QS_TOPK_K;
+#pragma unroll
+        for (int j = 0; j < QS_TOPK_K; j += 2)
+          *reinterpret_cast<ulonglong2*>(dst + j) = make_ulonglong2(tk_lst[g][j], tk_lst[g][j + 1]);
+      }
     } else if constexpr (MODE == QM_ARGMAX) {
       const float v2 = __shfl_xor(st_a[g], 32);
       const int i2 = __shfl_xor(st_i[g], 32);
@@ -479,7 +569,7 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int
 
 template <int D, int SPW, int MODE, int NBUF, int MINW>
 static void qs_launch_n(const QArgs& a, int64_t rblks, hipStream_t s) {
-  constexpr int smem = NBUF * QCfg<D>::BUF_BYTES;
+  constexpr int smem = NBUF * QCfg<D>::BUF_BYTES + (MODE == QM_TOPK ? 4 * SPW * QS_TOPK_BUF * 64 * 8 : 0);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)qstream_kernel<D, SPW, MODE, NBUF, MINW>,
@@ -512,8 +602,9 @@ static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
 }
 
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
-  static const int phase_of[7] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
-                                  CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE, CQLREC_PH_QHEAD_LSE};
+  static const int phase_of[8] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
+                                  CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE, CQLREC_PH_QHEAD_LSE,
+                                  CQLREC_PH_TOPK_TILEMAX};
   CqlProfScope prof(phase_of[mode], s);
   switch (mode) {
     case QM_LSE:
@@ -525,6 +616,7 @@ int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
     case QM_TILEMAX:
       if (qs_spw_fwd(d) == 4) return qs_launch_mode<QM_TILEMAX, 4>(a, d, rblks, s);
       return qs_launch_mode<QM_TILEMAX, 2>(a, d, rblks, s);
+    case QM_TOPK: return qs_launch_mode<QM_TOPK, 2>(a, d, rblks, s);
     case QM_BWD_DH: return qs_launch_mode<QM_BWD_DH, QS_SPW_BWD>(a, d, rblks, s);
     case QM_BWD_DE: return qs_launch_mode<QM_BWD_DE, QS_SPW_BWD>(a, d, rblks, s);
     case QM_LSE_DH: return qs_launch_mode<QM_LSE_DH, QS_SPW_BWD>(a, d, rblks, s);

@@ -8,6 +8,9 @@
 #define QM_BWD_DH 4
 #define QM_BWD_DE 5
 #define QM_LSE_DH 6         // forward logsumexp AND the softmax-weighted item sum (the soft part of dH) in one pass
+#define QM_TOPK 7           // running top-k (k <= 16) per user in the epilogue: no score or group maximum leaves the chip
+#define QS_TOPK_K 16        // list length kept per (user, lane half, item slice)
+#define QS_TOPK_BUF 4       // candidates buffered per lane between two merges into the list
 
 #define QS_TI 64            // host-side unit of streamed rows (split boundaries are multiples of it)
 #define QS_SPW_FWD 2        // 32-row owner groups per wave, forward modes (64 states per wave, 256 per block)
@@ -43,6 +46,12 @@ struct QArgs {
   float* out_cs;
   float scale;
   int accumulate;            // direct output adds to out / out_cs instead of overwriting (rows are block-owned: no atomics)
+  // QM_TOPK: per (slice, user, lane half) the QS_TOPK_K best admissible candidates as sortable 64-bit keys
+  // (order-preserving score bits << 32 | ~candidate row), best first, 0 = none
+  unsigned long long* topk_keys;   // [nsplit][n_res][2][QS_TOPK_K]
+  int topk_k;                      // requested k (<= QS_TOPK_K): the pruning threshold is the k-th best so far
+  const uint32_t* seen_bits;       // [n_res][seen_w] bitmap of the rows to exclude per owner row (NULL: no filter)
+  int64_t seen_w;                  // 32-bit words per owner row
 };
 
 struct QSplit {
@@ -77,3 +86,23 @@ int64_t cql_qde_ws_bytes(int64_t batch, int64_t n_items, int32_t d);
 int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const uint16_t* E_b, const float* bias,
                    int64_t n_items, int32_t d, float scale, void* ws, int64_t ws_bytes, float* out, float* out_cs,
                    int accumulate, hipStream_t s);
+
+// qhead_topk2.hip: the top-K pass as a one-wave-per-SIMD kernel with on-chip selection (d = 128, k <= 16, whole catalogue)
+struct QTk2Args {
+  const uint16_t* H_b;          // [n_users x D] bf16 state vectors
+  int64_t n_users;
+  const uint16_t* E_b;          // [n_cand x D] bf16 item rows
+  const float* bias;            // [n_cand]
+  int64_t n_cand;
+  int64_t split_rows;           // item rows per slice (multiple of 64)
+  int nsplit;
+  const uint32_t* seen_bits;    // cql_topk2_seen_bits layout, or NULL (no filter)
+  unsigned long long* keys;     // [nsplit][n_users][2][QS_TOPK_K]
+  int k;
+};
+bool cql_topk2_supported(int d, int k, int64_t n_cand);
+void cql_topk2_split(int64_t n_users, int64_t n_cand, int* nsplit, int64_t* split_rows);
+int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand);
+int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
+                        int64_t n_cand, uint32_t* bits, hipStream_t s);
+int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);

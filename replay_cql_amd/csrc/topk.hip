@@ -556,7 +556,92 @@ __global__ __launch_bounds__(64) void topk_select_small_kernel(const uint16_t* _
 }
 
 // =============================================================================================================
+// k <= 16, fused form: the MFMA pass itself keeps, per user, lane half and item slice, the QS_TOPK_K best admissible
+// candidates (QM_TOPK epilogue of qstream_kernel: a candidate is looked at only if it beats the running k-th best; seen
+// items are dropped when a candidate is merged into the list).  What is left is this merge of the 2 * nsplit short
+// sorted lists of a user -- no group maxima in HBM, no transpose, no re-scoring pass.
+// One thread per user: k rounds of "largest head".  Keys sort as (score desc, candidate row asc); candidate rows are
+// ascending in the global item id, so this is the (score desc, item id asc) order of SURVEY 8.0 S7.
+// =============================================================================================================
+__global__ __launch_bounds__(256) void topk_merge_kernel(const unsigned long long* __restrict__ keys, int nsplit,
+                                                         int64_t n_users, const int32_t* __restrict__ item_ids, int k,
+                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                         int32_t* __restrict__ out_cnt) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_users) return;
+  const int nl = 2 * nsplit;
+  int head[64];                    // nl <= 64 lists (nsplit <= 32)
+  for (int l = 0; l < nl; ++l) head[l] = 0;
+  int cnt = 0;
+  for (int j = 0; j < k; ++j) {
+    unsigned long long best = 0ull;
+    int bl = -1;
+    for (int l = 0; l < nl; ++l) {
+      if (head[l] >= QS_TOPK_K) continue;
+      const int sp = l >> 1, hh = l & 1;
+      const unsigned long long v = keys[(((int64_t)sp * n_users + u) * 2 + hh) * QS_TOPK_K + head[l]];
+      if (v > best) {
+        best = v;
+        bl = l;
+      }
+    }
+    if (bl < 0) break;
+    head[bl] += 1;
+    const uint32_t c = ~(uint32_t)(best & 0xFFFFFFFFull);
+    out_idx[u * k + j] = item_ids ? item_ids[c] : (int32_t)c;
+    out_val[u * k + j] = f32_from_order_key((uint32_t)(best >> 32));
+    ++cnt;
+  }
+  for (int j = cnt; j < k; ++j) {
+    out_idx[u * k + j] = -1;
+    out_val[u * k + j] = NEG_INF_F;
+  }
+  out_cnt[u] = cnt;
+}
+
+// Seen lists -> one bitmap row per user of the chunk (bit c of row u set: candidate row c is excluded for u), so
+// that the scoring kernel decides "seen?" with ONE load per candidate that beats its bound.  288 GB of HBM make
+// n_users * n_cand / 8 bytes affordable (0.8 GB for 65536 users x 100 000 items); zeroing it is a memset at HBM rate.
+// One wave per user; the first entry of every 32-item word ORs in the entries that follow in the same word (lists are
+// ascending, so they are adjacent); atomicOr keeps an unsorted list merely slower, not wrong.
+__global__ __launch_bounds__(256) void topk_seen_bits_kernel(const int64_t* __restrict__ seen_off,
+                                                             const int32_t* __restrict__ seen_items,
+                                                             const int32_t* __restrict__ seen_rows, int64_t n_users,
+                                                             int64_t n_cand, int64_t W, uint32_t* __restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_users) return;
+  const int64_t srow = seen_rows ? (int64_t)seen_rows[u] : u;
+  const int64_t lo = seen_off[srow], hi = seen_off[srow + 1];
+  for (int64_t j = lo + lane; j < hi; j += 64) {
+    const int32_t id = seen_items[j];
+    if (id < 0 || id >= n_cand) continue;
+    const int32_t w = id >> 5;
+    if (j > lo && (seen_items[j - 1] >> 5) == w) continue;
+    uint32_t m = 1u << (id & 31);
+    for (int64_t jj = j + 1; jj < hi; ++jj) {
+      const int32_t id2 = seen_items[jj];
+      if ((id2 >> 5) != w) break;
+      m |= 1u << (id2 & 31);
+    }
+    atomicOr(&bits[u * W + w], m);
+  }
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+static inline int64_t tk_bits_words(int64_t n_cand) { return ((n_cand + 31) / 32 + 3) / 4 * 4; }
+#define TK_FUSED_MAX_SPLIT 32
+static QSplit tk_fused_split(int64_t n_cand, int64_t n_users, int d) {
+  (void)d;
+  QSplit sp = qs_choose_split(n_cand, n_users, 2, QS_TI, 512);      // 2 blocks per CU resident (LDS: ring + buffers)
+  if (sp.nsplit > TK_FUSED_MAX_SPLIT) {
+    const int64_t units = (n_cand + QS_TI - 1) / QS_TI;
+    const int64_t upb = (units + TK_FUSED_MAX_SPLIT - 1) / TK_FUSED_MAX_SPLIT;
+    sp.split_rows = upb * QS_TI;
+    sp.nsplit = (int)((n_cand + sp.split_rows - 1) / sp.split_rows);
+  }
+  return sp;
+}
 
 static int tk_tile_groups(int64_t n_cand, int* tg_out) {
   const int64_t tiles = (n_cand + 31) / 32;
@@ -572,7 +657,17 @@ extern "C" int64_t cqlrec_topk_ws_bytes(int64_t n_users, int64_t n_cand, int32_t
   int tg;
   const int ngroups = tk_tile_groups(n_cand, &tg);
   const int gstride = (ngroups + 63) / 64 * 64;
-  return align256((int64_t)ngroups * n_users * 4) + align256((int64_t)gstride * n_users * 4) + 256;
+  const int64_t two_pass = align256((int64_t)ngroups * n_users * 4) + align256((int64_t)gstride * n_users * 4);
+  int64_t fused = align256((int64_t)tk_fused_split(n_cand, n_users, d).nsplit * n_users * 2 * QS_TOPK_K * 8) +
+                  align256(n_users * tk_bits_words(n_cand) * 4);
+  if (cql_topk2_supported(d, k, n_cand)) {
+    int ns;
+    int64_t sr;
+    cql_topk2_split(n_users, n_cand, &ns, &sr);
+    const int64_t f2 = align256((int64_t)ns * n_users * 2 * QS_TOPK_K * 8) + align256(cql_topk2_bits_bytes(n_users, n_cand));
+    if (f2 > fused) fused = f2;
+  }
+  return (two_pass > fused ? two_pass : fused) + 256;
 }
 
 extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b,
@@ -586,12 +681,79 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   CQL_REQUIRE(k > 0 && k <= TK_MAX_K, "score_topk: k=%d out of range (1..%d)", k, TK_MAX_K);
   CQL_REQUIRE(seen_off == nullptr || seen_items != nullptr, "score_topk: seen_items is NULL");
   CQL_REQUIRE(ws_bytes >= cqlrec_topk_ws_bytes(n_users, n_cand, d, k), "score_topk: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  static const int fused_off = getenv("CQL_TOPK_FUSED") && getenv("CQL_TOPK_FUSED")[0] == '0';   // A/B knob; tests run both
+  static const int force_generic0 = getenv("CQL_TOPK_GENERIC") ? 1 : 0;
+  // d = 128: one wave per SIMD, selection on chip (qhead_topk2.hip)
+  static const int tk2_off = getenv("CQL_TOPK2") && getenv("CQL_TOPK2")[0] == '0';
+  if (!tk2_off && !fused_off && !force_generic0 && item_ids == nullptr && cql_topk2_supported(d, k, n_cand)) {
+    QTk2Args a2 = {};
+    a2.H_b = H_b;
+    a2.n_users = n_users;
+    a2.E_b = E_b;
+    a2.bias = b;
+    a2.n_cand = n_cand;
+    a2.k = k;
+    cql_topk2_split(n_users, n_cand, &a2.nsplit, &a2.split_rows);
+    a2.keys = (unsigned long long*)ws;
+    if (seen_off) {
+      uint32_t* bits = (uint32_t*)((char*)ws + align256((int64_t)a2.nsplit * n_users * 2 * QS_TOPK_K * 8));
+      CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
+      const int rc = cql_topk2_seen_bits(seen_off, seen_items, seen_rows, n_users, n_cand, bits, s);
+      if (rc != CQLREC_OK) return rc;
+      a2.seen_bits = bits;
+    }
+    {
+      CqlProfScope prof(CQLREC_PH_TOPK_TILEMAX, s);
+      const int rc = cql_topk2_run(a2, d, s);
+      if (rc != CQLREC_OK) return rc;
+    }
+    CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(cql_ceil_div(n_users, 256)), dim3(256), 0, s,
+                       (const unsigned long long*)ws, a2.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt);
+    CQL_LAUNCH_CHECK("score_topk (topk2)");
+    return CQLREC_OK;
+  }
+  // candidate subsets (item_ids) keep the two-pass form: the bitmap is indexed by candidate row = global item id
+  if (k <= QS_TOPK_K && !fused_off && !force_generic0 && item_ids == nullptr && n_cand < (1ll << 31)) {
+    const QSplit sp = tk_fused_split(n_cand, n_users, d);
+    uint32_t* bits = nullptr;
+    const int64_t W = tk_bits_words(n_cand);
+    if (seen_off) {
+      bits = (uint32_t*)((char*)ws + align256((int64_t)sp.nsplit * n_users * 2 * QS_TOPK_K * 8));
+      CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
+      if (hipMemsetAsync(bits, 0, (size_t)n_users * W * 4, s) != hipSuccess) {
+        cql_set_error("score_topk: hipMemsetAsync failed");
+        return CQLREC_ERR_HIP;
+      }
+      hipLaunchKernelGGL(topk_seen_bits_kernel, dim3(cql_ceil_div(n_users, 4)), dim3(256), 0, s, seen_off, seen_items,
+                         seen_rows, n_users, n_cand, W, bits);
+    }
+    QArgs a = {};
+    a.res = H_b;
+    a.n_res = n_users;
+    a.str = E_b;
+    a.n_str = n_cand;
+    a.str_scalar = b;
+    a.nsplit = sp.nsplit;
+    a.split_rows = sp.split_rows;
+    a.tg = 1;
+    a.topk_keys = (unsigned long long*)ws;
+    a.topk_k = k;
+    a.seen_bits = bits;
+    a.seen_w = W;
+    qs_launch(QM_TOPK, a, d, sp.rblks, s);
+    CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(cql_ceil_div(n_users, 256)), dim3(256), 0, s,
+                       (const unsigned long long*)ws, sp.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt);
+    CQL_LAUNCH_CHECK("score_topk (fused)");
+    return CQLREC_OK;
+  }
   int tg;
   const int ngroups = tk_tile_groups(n_cand, &tg);
   const int gstride = (ngroups + 63) / 64 * 64;
   float* tm = (float*)ws;
   float* tm_t = (float*)((char*)ws + align256((int64_t)ngroups * n_users * 4));
-  hipStream_t s = (hipStream_t)stream;
   // pass 1
   const int unit = (32 * tg > QS_TI) ? 32 * tg : QS_TI;
   const QSplit sp = qs_choose_split(n_cand, n_users, qs_spw_fwd(d), unit, QS_TARGET_BLOCKS);
