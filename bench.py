@@ -136,6 +136,25 @@ def parity_check(cfg, dev, d_off, d_items, d_rew, ref):
             "note": "oracle = this repo's CPU restatement (parity unpinned by the reference: it has no CQL path)"}
 
 
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def hbm_roofline(alg_bytes, ms, table_bytes, **extra):
+    """HBM roofline of one launch from ALGORITHMIC bytes.  `frac` is only a statement about HBM when the kernel's table
+    cannot sit in the 256 MiB Infinity Cache: for a resident table the algorithmic rate may exceed the HBM peak (rows
+    come from cache), so frac is null there and profiles/r02_hbm_traffic.json holds the measured FETCH_SIZE/WRITE_SIZE
+    evidence on tables of 512 MB - 1 GiB (gather: 5.6 TB/s Zipf, 7.5 TB/s uniform; Adam: 4.9 TB/s, traffic = algorithmic)."""
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    resident = table_bytes < INFINITY_CACHE_BYTES
+    r = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+         "frac": None if resident else min(ach / PEAK_HBM_GBS, 1.0), "traffic": None, "avg_ms": ms,
+         "algorithmic_bytes": int(alg_bytes), "table_bytes": int(table_bytes), "infinity_cache_resident": resident,
+         "big_table_evidence": "profiles/r02_hbm_traffic.json"}
+    r.update(extra)
+    return r
+
+
+
 def main():
     args = parse()
     cfg = dict(CONFIGS[args.config])
@@ -317,11 +336,7 @@ def main():
             g_ms = tk_ph["gather_fwd"][0] / tk_ph["gather_fwd"][1]
             lens_u = (off[1: nu + 1] - off[:nu]).clamp(max=L).float().mean().item()
             gb = nu * (lens_u * d * 2 + lens_u * 4) + nu * d * 2        # rows + indices in, bf16 state out
-            topk["roofline_gather"] = {"bound": "hbm", "achieved": gb / (g_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                                       "unit": "GB/s", "frac": gb / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": g_ms,
-                                       "states_per_launch": nu,
-                                       "note": "E_in (25.6 MB) is Infinity-Cache resident: algorithmic bytes are "
-                                               "gathered rows, served mostly from cache"}
+            topk["roofline_gather"] = hbm_roofline(gb, g_ms, table_bytes=NI * d * 2, states_per_launch=nu)
 
     if rank != 0:
         if world > 1:
@@ -385,14 +400,11 @@ def main():
         g_bytes = B * (lens * d * 2 + lens * 4) + B * d * 4
         if phases["gather_fwd"][1]:
             g_ms = phases["gather_fwd"][0] / phases["gather_fwd"][1]
-            out["roofline_gather"] = {"bound": "hbm", "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                                      "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                      "avg_ms": g_ms, "note": "E_in table (25.6 MB) is Infinity-Cache resident"}
+            out["roofline_gather"] = hbm_roofline(g_bytes, g_ms, table_bytes=NI * d * 2, states_per_launch=B)
         if phases["adam"][1]:
             a_ms = phases["adam"][0] / phases["adam"][1]
             a_bytes = int(core.layout.total) * 44
-            out["roofline_adam"] = {"bound": "hbm", "achieved": a_bytes / (a_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                                    "unit": "GB/s", "frac": a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "avg_ms": a_ms}
+            out["roofline_adam"] = hbm_roofline(a_bytes, a_ms, table_bytes=int(core.layout.total) * 20)
     if topk:
         out["topk"] = topk
     if world == 1 and not args.no_cpu_baseline:

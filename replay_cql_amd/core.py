@@ -490,6 +490,8 @@ class CQLCore:
         if seen is not None and seen_rows is None:
             seen_rows = torch.arange(n, dtype=torch.int32, device=self.device)
         chunk = max(1, min(chunk, n))
+        if seen is not None:    # the seen bitmap of a chunk (users x items bits) stays under 4 GiB
+            chunk = min(chunk, max(4096, int((4 << 30) // max(1, n_cand // 8)) // 256 * 256))
         ws_bytes = int(self.lib.cqlrec_topk_ws_bytes(chunk, n_cand, h.d, k))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         s = _stream()
