@@ -231,12 +231,15 @@ def main():
         torch.cuda.synchronize()
 
     loss_buf = torch.zeros(args.warmup + args.steps + 1, device=dev)
+    issue_s = [0.0]
 
     def run(n, base):
         # <=64 steps per call, pipelined across steps: one library call (single rank: the step loop is in C++,
         # cqlrec_train_steps) or the phased data-parallel loop around the two asynchronous gradient all-reduces
+        t_issue = time.perf_counter()
         for lo_ in range(0, n, 64):
             core.train_steps(min(64, n - lo_), loss_buf[base + lo_:])
+        issue_s[0] += time.perf_counter() - t_issue      # host time spent ENQUEUEING (no sync inside train_steps)
 
     if args.serial:
         N.check(lib.cqlrec_set_concurrency(0), "set_concurrency")
@@ -248,8 +251,10 @@ def main():
         dom = 1 << N.PHASES.index("qhead_bwd_de")
         N.check(lib.cqlrec_prof_select(0xFFFFFFFF if args.serial else dom), "prof_select")
         N.check(lib.cqlrec_prof_enable(1), "prof_enable")
+    issue_s[0] = 0.0
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
+    host_issue_ms_per_step = 1e3 * issue_s[0] / max(args.steps, 1)
     barrier()
     dt = time.perf_counter() - t0
     phases_timed = N.prof_read() if not args.no_prof else {}
@@ -355,6 +360,9 @@ def main():
                                   ("reduce-scatter, row-sharded Adam, bf16 all-gather)" if core.shard_optimizer else "all-reduce)"), "k": K,
                    "dp_variant": want, "dp_probe": dp_probe},
         "transitions_per_sec": world * args.steps * B / dt,
+        # time outside kernels: what the host (rank 0) spent enqueueing a step (launches, collectives' issue, Python);
+        # it runs ahead of the device, so it only bounds the step when it exceeds ms_per_step
+        "host_issue_ms_per_step": host_issue_ms_per_step,
         "loss_first_last": [losses[0], losses[-1]] if losses else None,
     }
     if phases:
@@ -378,13 +386,16 @@ def main():
                            "algorithmic_flops_per_launch": gemms[dom] * flops}
         # `traffic`: HBM bytes per launch from the PMC counters -- collected in separate rocprofv3 --pmc passes (they cannot
         # be read from inside this process) and committed with their provenance; only valid for the shape they were taken on
-        try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))          # a malformed file is an error, not a silent null
             if pmc["config"] == {"batch": B, "items": NI, "d": d} and dom in pmc["kernels"]:
                 out["roofline"]["traffic"] = pmc["kernels"][dom]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = pmc["source"] + "; " + pmc["correction"]
-        except (OSError, ValueError, KeyError):
-            pass
+            else:
+                out["roofline"]["traffic_note"] = "profiles/pmc_traffic.json holds no counters for this shape/kernel"
+        else:
+            out["roofline"]["traffic_note"] = "profiles/pmc_traffic.json not found"
         out["roofline_qhead_kernels"] = {
             p: {"avg_ms": round(ms, 4), "algorithmic_tflops": round(gemms[p] * flops / (ms * 1e-3) / 1e12, 1),
                 "frac": round(gemms[p] * flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)} for p, ms in qk.items()}
