@@ -77,6 +77,7 @@ class CQLCore:
         # the all-reduce, 1/W of the Adam traffic per GPU.  Opt-in; needs world > 1 and N >= W.
         self.shard_optimizer = bool(shard_optimizer) and self.world > 1 and self.n_items >= self.world
         self._gshard: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+        self._tailpack: Optional[torch.Tensor] = None
         self.init_params(init_seed)
 
     # ------------------------------------------------------------------ parameters
@@ -303,6 +304,10 @@ class CQLCore:
             self._gshard = (torch.empty(P["n"], dtype=torch.float32, device=self.device),
                             torch.empty(P["n"], dtype=torch.float32, device=self.device))
         g_in, g_out = self._gshard
+        if self._tailpack is None:
+            self._tailpack = torch.empty((P["tail_in"][1] - P["tail_in"][0]) + (P["tail_enc"][1] - P["tail_enc"][0]),
+                                         dtype=torch.float32, device=self.device)
+        pk = self._tailpack
         side = self._side
         ev_fwd, ev_rest, ev_items = self._ev
         pg = self.pg
@@ -337,9 +342,15 @@ class CQLCore:
             # its gradients are ready first, and its whole exchange (reduce-scatter, Adam on the own rows, all-gather
             # of the shadows the next prologue reads) then runs under the item-side kernel; the item side queues behind.
             w_in = reduce_scatter_sum(g_in, self.grads[P["in_region"][0]: P["in_region"][1]], pg, async_op=True)
-            w_t1, w_t2 = ar(*P["tail_in"]), ar(*P["tail_enc"])
-            wait(w_in), wait(w_t1), wait(w_t2)
+            # the two replicated remainders of the state side (last rows of E_in, encoder) travel as ONE all-reduce
+            n1 = P["tail_in"][1] - P["tail_in"][0]
+            pk[:n1].copy_(self.grads[P["tail_in"][0]: P["tail_in"][1]])
+            pk[n1:].copy_(self.grads[P["tail_enc"][0]: P["tail_enc"][1]])
+            w_t = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+            wait(w_in), wait(w_t)
             self._adam_shard(P["in_own"][0], P["in_own"][1], g_in, s)
+            self.grads[P["tail_in"][0]: P["tail_in"][1]].copy_(pk[:n1])
+            self.grads[P["tail_enc"][0]: P["tail_enc"][1]].copy_(pk[n1:])
             upd(P["tail_in"][0], P["tail_in"][1], s)
             upd(P["tail_enc"][0], P["tail_enc"][1], s)
             self.grads[P["in_region"][0]: P["in_region"][1]].zero_()
