@@ -294,22 +294,19 @@ def main():
         rows = torch.repeat_interleave(torch.arange(hi - lo, device=dev), off[1:] - off[:-1])
         seen_items = items[torch.argsort(rows * NI + items.to(torch.int64))].contiguous()
         del rows
-        hb = core.encode(off, items, users)
-        core.score_topk(hb[:1024], K, seen=(off, seen_items), chunk=nu)      # warm-up
+        core.encode_topk(off, items, users[:1024], K, seen=(off, seen_items), chunk=nu)      # warm-up
         barrier()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            hb = core.encode(off, items, users)
-            idx, val, cnt = core.score_topk(hb, K, seen=(off, seen_items), chunk=nu)
+            idx, val, cnt = core.encode_topk(off, items, users, K, seen=(off, seen_items), chunk=nu)
         barrier()
         dtk = time.perf_counter() - t1
         # per-kernel durations from one more, event-bracketed pass (not part of `value`: the brackets cost ~8 % here)
         tk_ph = {}
         if not args.no_prof:
             N.check(lib.cqlrec_prof_enable(1), "prof_enable")
-            hb = core.encode(off, items, users)
-            core.score_topk(hb, K, seen=(off, seen_items), chunk=nu)
+            core.encode_topk(off, items, users, K, seen=(off, seen_items), chunk=nu)
             barrier()
             tk_ph = N.prof_read()
             N.check(lib.cqlrec_prof_enable(0), "prof_enable")

@@ -202,6 +202,18 @@ int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b,
                       int32_t d, const int32_t* item_ids, const int64_t* seen_off, const int32_t* seen_items,
                       const int32_t* seen_rows, int32_t k, void* ws, int64_t ws_bytes, int32_t* out_idx,
                       float* out_val, int32_t* out_cnt, cqlrec_stream stream);
+/* The same in two phases, so that the part that depends on the seen lists only (their bitmap, built in `ws`: it is
+ * what _filter_seen's anti-join becomes here) can run on another stream while the caller still encodes the state
+ * vectors:  CQLREC_TOPK_SEEN (H_b, outputs ignored; may be NULL) ... CQLREC_TOPK_SCORE on the same ws, ordered
+ * behind it by the caller.  CQLREC_TOPK_ALL = cqlrec_score_topk.  Shapes whose selection kernel filters on the
+ * fly do nothing in the first phase. */
+#define CQLREC_TOPK_ALL 0
+#define CQLREC_TOPK_SEEN 1
+#define CQLREC_TOPK_SCORE 2
+int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b, int64_t n_cand,
+                            int32_t d, const int32_t* item_ids, const int64_t* seen_off, const int32_t* seen_items,
+                            const int32_t* seen_rows, int32_t k, void* ws, int64_t ws_bytes, int32_t* out_idx,
+                            float* out_val, int32_t* out_cnt, int32_t phase, cqlrec_stream stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a8  Whole training step = TorchRecommender._run_train_step (replay/models/base_torch_rec.py:32-39) without

@@ -15,6 +15,7 @@ _LIB_PATH = Path(os.environ["CQLREC_LIB"]).resolve() if os.environ.get("CQLREC_L
 _lib: Optional[C.CDLL] = None
 
 ABI_VERSION = 2
+TOPK_ALL, TOPK_SEEN, TOPK_SCORE = 0, 1, 2
 QHEAD_LSE = 1
 QHEAD_ARGMAX = 2
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "cqlrec_cast_bf16": (i32, [vp, vp, i64, vp]),
     "cqlrec_topk_ws_bytes": (i64, [i64, i64, i32, i32]),
     "cqlrec_score_topk": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, vp]),
+    "cqlrec_score_topk_phase": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, i32, vp]),
     "cqlrec_train_ws_bytes": (i64, [i32, i64, i32, i32]),
     "cqlrec_train_step_fwd_bwd": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
     "cqlrec_train_step_update": (i32, [C.POINTER(TrainCtx), u64, vp]),

@@ -78,6 +78,7 @@ class CQLCore:
         self.shard_optimizer = bool(shard_optimizer) and self.world > 1 and self.n_items >= self.world
         self._gshard: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._tailpack: Optional[torch.Tensor] = None
+        self._topk_side: Optional[torch.cuda.Stream] = None
         self.init_params(init_seed)
 
     # ------------------------------------------------------------------ parameters
@@ -477,9 +478,14 @@ class CQLCore:
                    seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
                    chunk: int = 65536) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Top-k (score desc, item id asc) for the state vectors hb.  cand_items: ascending int32 global ids (None =
-        whole catalog).  seen = (offsets int64, ascending item ids int32) CSR; seen_rows maps hb rows to CSR rows."""
+        whole catalog).  seen = (offsets int64, ascending item ids int32) CSR; seen_rows maps hb rows to CSR rows.
+        hb may also be a pair (n, fn) with fn(lo, hi) -> bf16 state vectors of rows [lo, hi): the vectors of a chunk are
+        then produced while the chunk's seen bitmap is built on a side stream (encode_topk)."""
         h, lay = self.hyper, self.layout
-        n = hb.shape[0]
+        if isinstance(hb, tuple):
+            n, hb = int(hb[0]), hb[1]
+        else:
+            n = hb.shape[0]
         if k > self.MAX_FUSED_K:
             return self._score_topk_large_k(hb, k, cand_items, seen, seen_rows, chunk)
         eb, fp = self.theta_b.data_ptr(), self.theta.data_ptr()
@@ -505,19 +511,50 @@ class CQLCore:
             chunk = min(chunk, max(4096, int((4 << 30) // max(1, n_cand // 8)) // 256 * 256))
         ws_bytes = int(self.lib.cqlrec_topk_ws_bytes(chunk, n_cand, h.d, k))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-        s = _stream()
+        main = torch.cuda.current_stream()
+        s = main.cuda_stream
+        hb_fn = hb if callable(hb) else None
+        if hb_fn is not None and self._topk_side is None:
+            self._topk_side = torch.cuda.Stream(device=self.device)
         for lo in range(0, n, chunk):
             hi = min(n, lo + chunk)
             rows_ptr = None if seen_rows is None else seen_rows.data_ptr() + 4 * lo
-            N.check(self.lib.cqlrec_score_topk(
-                hb.data_ptr() + 2 * h.d * lo, hi - lo, E_ptr, b_ptr, n_cand, h.d, ids_ptr,
-                None if seen is None else _ptr(seen[0]), None if seen is None else _ptr(seen[1]), rows_ptr, k,
-                _ptr(ws), ws_bytes, out_idx.data_ptr() + 4 * k * lo, out_val.data_ptr() + 4 * k * lo,
-                out_cnt.data_ptr() + 4 * lo, s), "score_topk")
+
+            def call(hptr, phase, stream):
+                N.check(self.lib.cqlrec_score_topk_phase(
+                    hptr, hi - lo, E_ptr, b_ptr, n_cand, h.d, ids_ptr,
+                    None if seen is None else _ptr(seen[0]), None if seen is None else _ptr(seen[1]), rows_ptr, k,
+                    _ptr(ws), ws_bytes, out_idx.data_ptr() + 4 * k * lo, out_val.data_ptr() + 4 * k * lo,
+                    out_cnt.data_ptr() + 4 * lo, phase, stream), "score_topk")
+            if hb_fn is None:
+                call(hb.data_ptr() + 2 * h.d * lo, N.TOPK_ALL, s)
+            else:
+                # the seen bitmap of the chunk does not depend on the state vectors: it is built on a side stream
+                # while the encoder runs on this one
+                side = self._topk_side
+                side.wait_stream(main)          # (the previous chunk's scoring reads the same workspace)
+                call(None, N.TOPK_SEEN, side.cuda_stream)
+                hb_c = hb_fn(lo, hi)
+                main.wait_stream(side)
+                call(hb_c.data_ptr(), N.TOPK_SCORE, s)
+                hb_c.record_stream(main)
         del keep
         return out_idx, out_val, out_cnt
 
     MAX_FUSED_K = 2048
+
+    def encode_topk(self, offsets: torch.Tensor, items: torch.Tensor, users: torch.Tensor, k: int,
+                    cand_items: Optional[torch.Tensor] = None,
+                    seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
+                    chunk: int = 65536) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """encode(offsets, items, users) + score_topk in one pipelined pass (the predict path, S7): per chunk of users the
+        seen bitmap is built on a side stream while the window gather and the encoder run."""
+        if seen is not None and seen_rows is None:
+            seen_rows = users.to(device=self.device, dtype=torch.int32)
+        if k > self.MAX_FUSED_K:
+            return self.score_topk(self.encode(offsets, items, users), k, cand_items, seen, seen_rows, chunk)
+        return self.score_topk((users.numel(), lambda lo, hi: self.encode(offsets, items, users[lo:hi])), k, cand_items,
+                               seen, seen_rows, chunk)
 
     def _score_topk_large_k(self, hb, k, cand_items, seen, seen_rows, chunk):
         """k beyond the fused kernel's limit (full-ranking requests): rank every candidate part of <= MAX_FUSED_K items

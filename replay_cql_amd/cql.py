@@ -236,9 +236,9 @@ class CQL(PandasRecommender):
             cand = cand[cand < core.n_items]
             if cand.numel() == core.n_items:
                 cand = None
-        hb = core.encode(offsets, items, users32)
-        idx, val, cnt = core.score_topk(hb, int(k), cand_items=cand, seen=None if seen is None else (offsets, seen),
-                                        seen_rows=users32 if seen is not None else None)
+        idx, val, cnt = core.encode_topk(offsets, items, users32, int(k), cand_items=cand,
+                                         seen=None if seen is None else (offsets, seen),
+                                         seen_rows=users32 if seen is not None else None)
         return users32, idx, val, cnt
 
     def _predict(self, log: Optional[pd.DataFrame], k: int, users: pd.DataFrame, items: pd.DataFrame,

@@ -434,32 +434,53 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
 }
 
 // =============================================================================================================
-// seen lists -> bitmap in the layout above.  One wave per user; the first entry of every 32-item word ORs in the entries
-// that follow in the same word (lists are ascending, so they are adjacent); atomicOr keeps an unsorted list merely
-// slower, not wrong.  The buffer is zeroed by the caller.
+// seen lists -> bitmap in the layout above, written DENSELY: one block per 64-user block, the bitmap of TK2_BCH stages at
+// a time is assembled in LDS (zero, OR the users' entries of that item range in, write out with 16-byte stores) -- every
+// byte of the bitmap is written exactly once, nothing is zeroed beforehand and no read-modify-write reaches HBM
+// (memset + atomicOr per entry took 0.30 ms for 65536 users x 100 000 items; the bitmap alone is 0.13 ms of writes).
+// The lists are ASCENDING (cqlrec.h): four threads per user walk a list with one cursor per user.
 // =============================================================================================================
+#define TK2_BCH 96      // stages per LDS tile: 96 x 512 B = 48 KiB
 __global__ __launch_bounds__(256) void topk2_seen_bits_kernel(const int64_t* __restrict__ seen_off,
                                                               const int32_t* __restrict__ seen_items,
                                                               const int32_t* __restrict__ seen_rows, int64_t n_users,
                                                               int64_t n_cand, int64_t nst_all, uint32_t* __restrict__ bits) {
-  const int lane = threadIdx.x & 63;
-  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (u >= n_users) return;
-  const int64_t srow = seen_rows ? (int64_t)seen_rows[u] : u;
-  const int64_t lo = seen_off[srow], hi = seen_off[srow + 1];
-  uint32_t* base = bits + (u >> 6) * nst_all * 128 + (u & 63) * 2;
-  for (int64_t j = lo + lane; j < hi; j += 64) {
-    const int32_t id = seen_items[j];
-    if (id < 0 || id >= n_cand) continue;
-    const int32_t w = id >> 5;
-    if (j > lo && (seen_items[j - 1] >> 5) == w) continue;
-    uint32_t m = 1u << (id & 31);
-    for (int64_t jj = j + 1; jj < hi; ++jj) {
-      const int32_t id2 = seen_items[jj];
-      if ((id2 >> 5) != w) break;
-      m |= 1u << (id2 & 31);
+  __shared__ __attribute__((aligned(16))) uint32_t tile[TK2_BCH * 128];     // [stage][user][2 words]
+  const int t = threadIdx.x, user = t >> 2, q = t & 3;
+  const int64_t u = (int64_t)blockIdx.x * 64 + user;
+  int64_t cur = 0, end = 0;                 // this user's entries not yet placed (kept in step by its four threads)
+  if (u < n_users) {
+    const int64_t srow = seen_rows ? (int64_t)seen_rows[u] : u;
+    cur = seen_off[srow];
+    end = seen_off[srow + 1];
+  }
+  uint32_t* dst = bits + (int64_t)blockIdx.x * nst_all * 128;
+  for (int64_t st0 = 0; st0 < nst_all; st0 += TK2_BCH) {
+    const int nst = (int)((nst_all - st0 < TK2_BCH) ? (nst_all - st0) : TK2_BCH);
+    for (int i = t; i < nst * 32; i += 256) reinterpret_cast<uint4*>(tile)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int64_t item_lo = st0 * 64, item_hi = (st0 + nst) * 64;
+    int64_t j = cur + q;
+    for (; j < end; j += 4) {
+      const int32_t id = seen_items[j];
+      if (id >= item_hi) break;
+      if (id >= item_lo && id < n_cand)
+        atomicOr(&tile[(int)((id >> 6) - st0) * 128 + user * 2 + ((id >> 5) & 1)], 1u << (id & 31));
     }
-    atomicOr(base + (int64_t)(w >> 1) * 128 + (w & 1), m);
+    if (j > end) j = end;
+    // first entry at or beyond item_hi = the smallest of the four stopping points (ascending list, stride 4)
+    int64_t b = j;
+    {
+      const int64_t o1 = __shfl_xor(b, 1, 4);
+      b = (o1 < b) ? o1 : b;
+      const int64_t o2 = __shfl_xor(b, 2, 4);
+      b = (o2 < b) ? o2 : b;
+    }
+    cur = b;
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(dst + st0 * 128);
+    for (int i = t; i < nst * 32; i += 256) out[i] = reinterpret_cast<const uint4*>(tile)[i];
+    __syncthreads();
   }
 }
 
@@ -501,11 +522,7 @@ int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand) {
 
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
                         int64_t n_cand, uint32_t* bits, hipStream_t s) {
-  if (hipMemsetAsync(bits, 0, (size_t)cql_topk2_bits_bytes(n_users, n_cand), s) != hipSuccess) {
-    cql_set_error("score_topk: hipMemsetAsync failed");
-    return CQLREC_ERR_HIP;
-  }
-  hipLaunchKernelGGL(topk2_seen_bits_kernel, dim3((unsigned)((n_users + 3) / 4)), dim3(256), 0, s, seen_off, seen_items,
+  hipLaunchKernelGGL(topk2_seen_bits_kernel, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off, seen_items,
                      seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits);
   CQL_LAUNCH_CHECK("topk2_seen_bits");
   return CQLREC_OK;

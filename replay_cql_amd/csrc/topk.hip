@@ -675,6 +675,37 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
                                  const int32_t* seen_items, const int32_t* seen_rows, int32_t k, void* ws,
                                  int64_t ws_bytes, int32_t* out_idx, float* out_val, int32_t* out_cnt,
                                  cqlrec_stream stream) {
+  return cqlrec_score_topk_phase(H_b, n_users, E_b, b, n_cand, d, item_ids, seen_off, seen_items, seen_rows, k, ws, ws_bytes,
+                                 out_idx, out_val, out_cnt, CQLREC_TOPK_ALL, stream);
+}
+
+// does this shape take the on-chip-selection kernel (whose seen bitmap cqlrec_score_topk_phase can build ahead)?
+static bool tk_uses_topk2(int32_t d, int32_t k, int64_t n_cand, const int32_t* item_ids) {
+  static const int fused_off = getenv("CQL_TOPK_FUSED") && getenv("CQL_TOPK_FUSED")[0] == '0';
+  static const int force_generic0 = getenv("CQL_TOPK_GENERIC") ? 1 : 0;
+  static const int tk2_off = getenv("CQL_TOPK2") && getenv("CQL_TOPK2")[0] == '0';
+  return !tk2_off && !fused_off && !force_generic0 && item_ids == nullptr && cql_topk2_supported(d, k, n_cand);
+}
+
+extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b,
+                                       int64_t n_cand, int32_t d, const int32_t* item_ids, const int64_t* seen_off,
+                                       const int32_t* seen_items, const int32_t* seen_rows, int32_t k, void* ws,
+                                       int64_t ws_bytes, int32_t* out_idx, float* out_val, int32_t* out_cnt,
+                                       int32_t phase, cqlrec_stream stream) {
+  CQL_REQUIRE(phase == CQLREC_TOPK_ALL || phase == CQLREC_TOPK_SEEN || phase == CQLREC_TOPK_SCORE,
+              "score_topk: phase=%d", phase);
+  if (phase == CQLREC_TOPK_SEEN) {     // the part that does not depend on the state vectors
+    CQL_REQUIRE(ws && n_users > 0 && n_cand > 0, "score_topk (seen phase): bad arguments");
+    CQL_REQUIRE(ws_bytes >= cqlrec_topk_ws_bytes(n_users, n_cand, d, k), "score_topk: workspace too small");
+    if (!seen_off || !tk_uses_topk2(d, k, n_cand, item_ids)) return CQLREC_OK;   // other forms filter while they select
+    CQL_REQUIRE(seen_items != nullptr, "score_topk: seen_items is NULL");
+    int ns;
+    int64_t sr;
+    cql_topk2_split(n_users, n_cand, &ns, &sr);
+    uint32_t* bits = (uint32_t*)((char*)ws + align256((int64_t)ns * n_users * 2 * QS_TOPK_K * 8));
+    CqlProfScope prof(CQLREC_PH_TOPK_SELECT, (hipStream_t)stream);
+    return cql_topk2_seen_bits(seen_off, seen_items, seen_rows, n_users, n_cand, bits, (hipStream_t)stream);
+  }
   CQL_REQUIRE(H_b && E_b && b && ws && out_idx && out_val && out_cnt, "score_topk: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "score_topk: d=%d unsupported", d);
   CQL_REQUIRE(n_users > 0 && n_cand > 0, "score_topk: n_users=%lld n_cand=%lld", (long long)n_users, (long long)n_cand);
@@ -685,8 +716,7 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
   static const int fused_off = getenv("CQL_TOPK_FUSED") && getenv("CQL_TOPK_FUSED")[0] == '0';   // A/B knob; tests run both
   static const int force_generic0 = getenv("CQL_TOPK_GENERIC") ? 1 : 0;
   // d = 128: one wave per SIMD, selection on chip (qhead_topk2.hip)
-  static const int tk2_off = getenv("CQL_TOPK2") && getenv("CQL_TOPK2")[0] == '0';
-  if (!tk2_off && !fused_off && !force_generic0 && item_ids == nullptr && cql_topk2_supported(d, k, n_cand)) {
+  if (tk_uses_topk2(d, k, n_cand, item_ids)) {
     QTk2Args a2 = {};
     a2.H_b = H_b;
     a2.n_users = n_users;
@@ -698,9 +728,11 @@ extern "C" int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uin
     a2.keys = (unsigned long long*)ws;
     if (seen_off) {
       uint32_t* bits = (uint32_t*)((char*)ws + align256((int64_t)a2.nsplit * n_users * 2 * QS_TOPK_K * 8));
-      CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
-      const int rc = cql_topk2_seen_bits(seen_off, seen_items, seen_rows, n_users, n_cand, bits, s);
-      if (rc != CQLREC_OK) return rc;
+      if (phase == CQLREC_TOPK_ALL) {
+        CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
+        const int rc = cql_topk2_seen_bits(seen_off, seen_items, seen_rows, n_users, n_cand, bits, s);
+        if (rc != CQLREC_OK) return rc;
+      }
       a2.seen_bits = bits;
     }
     {

@@ -257,3 +257,28 @@ def test_cfg5_shard_shape_properties():
         for j in set(idx[u].tolist()) ^ set(ri[u, :k].tolist()):
             assert abs(Q[u, j].item() - kth) < 1e-4
         torch.testing.assert_close(val[u], Q[u, idx[u].long()], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("d,chunk", [(128, 1536), (64, 4000)])
+def test_encode_topk_pipelined_equals_two_calls(d, chunk):
+    """core.encode_topk (seen bitmap of a chunk built on a side stream while the chunk is encoded, several chunks
+    through one workspace) returns exactly what encode() followed by score_topk() returns."""
+    U, Nn, L, k = 4000, 5000, 20, 10
+    off, items, rew = synth_log_device(U, Nn, seed=777, device=DEV)
+    core = CQLCore(Nn, CQLHyper(d=d, window=L, batch=256, seed=0), device=DEV)
+    core.set_log(off, items, rew)
+    core.train(3)
+    users = torch.randperm(U, generator=torch.Generator().manual_seed(5))[:3500].to(DEV).to(torch.int32)
+    rows = torch.repeat_interleave(torch.arange(U, device=DEV), off[1:] - off[:-1])
+    seen = items[torch.argsort(rows * Nn + items.to(torch.int64))].contiguous()
+    hb = core.encode(off, items, users)
+    ref = core.score_topk(hb, k, seen=(off, seen), seen_rows=users)
+    for _ in range(2):            # twice: the second pass reuses streams and events of the first
+        got = core.encode_topk(off, items, users, k, seen=(off, seen), chunk=chunk)
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    got = core.encode_topk(off, items, users, k, chunk=chunk)          # no filter
+    ref = core.score_topk(hb, k)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)

@@ -37,7 +37,9 @@ def phases(fn):
     return {k: (round(v[0], 4), v[1]) for k, v in ph.items() if v[1]}
 tag = "fused=%s" % os.environ.get("CQL_TOPK_FUSED", "1")
 for name, fn in (("no seen", lambda: core.score_topk(hb, a.k, chunk=U)),
-                 ("seen", lambda: core.score_topk(hb, a.k, seen=(off, seen_items), chunk=U))):
+                 ("seen", lambda: core.score_topk(hb, a.k, seen=(off, seen_items), chunk=U)),
+                 ("encode+seen (pipelined)", lambda: core.encode_topk(off, items, users, a.k, seen=(off, seen_items),
+                                                                      chunk=U))):
     ms = t(fn)
     print(f"{tag} U={U} N={NI} d={a.d} k={a.k} train={a.train} {name}: {ms:.3f} ms  {U / ms * 1e-3:.2f} M users/s  "
           f"MFMA frac {2.0 * U * NI * a.d / (ms * 1e-3) / 2.5e15:.3f}  phases {phases(fn)}", flush=True)
