@@ -102,3 +102,21 @@ __device__ __forceinline__ float f32_from_order_key(uint32_t k) {
   uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
   return __uint_as_float(u);
 }
+
+// Deferred sum of the cut pieces of the item-side backward (qhead_de.hip).  The persistent kernel writes the piece of a
+// cut item group that does not hold stage 0 to a slab; qde_fixup_kernel adds those slabs to the gradient rows.  The
+// single-rank step driver skips that launch: the Adam launch that consumes g_E_out / g_b_out right behind it adds the
+// same slabs, in the same order, while it reads the gradient (cql_adam_ema_fix) -- one launch and one read-modify-write
+// of the cut rows less on the step's critical path.
+struct CqlAdamFix {
+  int valid;                // 0: nothing deferred (the gradient is complete)
+  const float* slab;        // [nblk][items x D]
+  const float* slab_cs;     // [nblk][items]
+  int32_t G, T, nblk, items, D;
+  float scale;
+  int64_t n_items;
+  int64_t rows_off, cs_off; // element offsets of g_E_out / g_b_out inside the updated range
+};
+int cql_adam_ema_fix(float* theta, float* grads, float* m, float* v, float* target, uint16_t* theta_b, uint16_t* target_b,
+                     int64_t n, float step_size, float sqrt_bc2, float beta1, float beta2, float eps, float tau,
+                     int32_t zero_grads, const CqlAdamFix* fix, hipStream_t stream);

@@ -656,6 +656,98 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ thet
   }
 }
 
+// what qde_fixup_kernel would have added to the four gradient elements 4 i4 .. 4 i4 + 3 (relative to the start of the
+// updated range).  D and the items per group are powers of two and every offset is a multiple of 4, so the four elements
+// belong to one item (rows) or to four items of one group (column sums); 32-bit arithmetic (the host checks the range).
+__device__ __forceinline__ void adam_fix4(const CqlAdamFix& f, float (&g)[4], int64_t i4, int ld, int li) {
+  const int64_t e = 4 * i4;
+  uint32_t item;
+  int col = -1;
+  if (e >= f.rows_off && e < f.rows_off + f.n_items * f.D) {
+    const uint64_t r = (uint64_t)(e - f.rows_off);
+    item = (uint32_t)(r >> ld);
+    col = (int)(r & (uint64_t)(f.D - 1));
+  } else if (e >= f.cs_off && e < f.cs_off + f.n_items) {
+    item = (uint32_t)(e - f.cs_off);
+  } else {
+    return;
+  }
+  const uint32_t grp = item >> li, row = item & (uint32_t)(f.items - 1);
+  const uint32_t W = (uint32_t)f.G * (uint32_t)f.T, nblk = (uint32_t)f.nblk, lo = grp * (uint32_t)f.T, hi = lo + (uint32_t)f.T;
+  for (uint32_t p = ((lo + 1) * nblk + W - 1) / W; p < nblk; ++p) {     // the pieces, in block order
+    const uint32_t u0 = (uint32_t)((uint64_t)p * W / nblk);
+    if (u0 >= hi) break;
+    if (u0 <= lo) continue;
+    if ((uint32_t)(((uint64_t)p + 1) * W / nblk) == u0) continue;
+    if (col >= 0) {
+      const float4 s4 = *reinterpret_cast<const float4*>(f.slab + ((int64_t)p * f.items + row) * f.D + col);
+      g[0] += f.scale * s4.x; g[1] += f.scale * s4.y; g[2] += f.scale * s4.z; g[3] += f.scale * s4.w;
+    } else {
+      const float* sc = f.slab_cs + (int64_t)p * f.items + row;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((int64_t)item + k < f.n_items) g[k] += f.scale * sc[k];
+    }
+  }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void adam_ema_fix_kernel(float4* __restrict__ theta, float4* __restrict__ grads,
+                                                           float4* __restrict__ m, float4* __restrict__ v,
+                                                           float4* __restrict__ target, uint2* __restrict__ theta_b,
+                                                           uint2* __restrict__ target_b, int64_t n4, float step_size,
+                                                           float sqrt_bc2, float beta1, float beta2, float eps, float tau,
+                                                           int zero_grads, CqlAdamFix fix) {
+  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2, omt = 1.0f - tau;
+  const int ld = __builtin_ctz((unsigned)fix.D), li = __builtin_ctz((unsigned)fix.items);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 g4 = ld4<NT>(grads + i);
+    float4 p4 = ld4<NT>(theta + i), m4 = ld4<NT>(m + i), v4 = ld4<NT>(v + i), t4 = ld4<NT>(target + i);
+    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    adam_fix4(fix, g, i, ld, li);
+    float p[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w},
+          tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mm[k] = beta1 * mm[k] + omb1 * g[k];
+      vv[k] = beta2 * vv[k] + (omb2 * g[k]) * g[k];
+      const float denom = sqrtf(vv[k]) / sqrt_bc2 + eps;
+      p[k] = p[k] - step_size * (mm[k] / denom);
+      tt[k] = omt * tt[k] + tau * p[k];
+    }
+    st4<NT>(theta + i, p[0], p[1], p[2], p[3]);
+    st4<NT>(m + i, mm[0], mm[1], mm[2], mm[3]);
+    st4<NT>(v + i, vv[0], vv[1], vv[2], vv[3]);
+    st4<NT>(target + i, tt[0], tt[1], tt[2], tt[3]);
+    theta_b[i] = make_uint2(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]));
+    target_b[i] = make_uint2(pack_bf16x2(tt[0], tt[1]), pack_bf16x2(tt[2], tt[3]));
+    if (zero_grads) st4<NT>(grads + i, 0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+int cql_adam_ema_fix(float* theta, float* grads, float* m, float* v, float* target, uint16_t* theta_b, uint16_t* target_b,
+                     int64_t n, float step_size, float sqrt_bc2, float beta1, float beta2, float eps, float tau,
+                     int32_t zero_grads, const CqlAdamFix* fix, hipStream_t stream) {
+  const bool pow2 = fix && fix->valid && (fix->D & (fix->D - 1)) == 0 && (fix->items & (fix->items - 1)) == 0 &&
+                    fix->rows_off % 4 == 0 && fix->cs_off % 4 == 0 &&
+                    (int64_t)fix->G * fix->T * ((int64_t)fix->nblk + 1) < (1ll << 31) && fix->n_items < (1ll << 31);
+  CQL_REQUIRE(!fix || !fix->valid || pow2, "adam_ema: deferred fix-up outside the supported range");
+  if (!fix || !fix->valid)
+    return cqlrec_adam_ema(theta, grads, m, v, target, theta_b, target_b, n, step_size, sqrt_bc2, beta1, beta2, eps, tau,
+                           zero_grads, (cqlrec_stream)stream);
+  CQL_REQUIRE(theta && grads && m && v && target && theta_b && target_b, "adam_ema: NULL pointer");
+  CQL_REQUIRE(n > 0 && n % 4 == 0, "adam_ema: n=%lld must be a positive multiple of 4", (long long)n);
+  const int64_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  CqlProfScope prof(CQLREC_PH_ADAM, stream);
+  hipLaunchKernelGGL(adam_ema_fix_kernel<true>, dim3(blocks), dim3(256), 0, stream, (float4*)theta, (float4*)grads,
+                     (float4*)m, (float4*)v, (float4*)target, (uint2*)theta_b, (uint2*)target_b, n4, step_size, sqrt_bc2,
+                     beta1, beta2, eps, tau, zero_grads, *fix);
+  CQL_LAUNCH_CHECK("adam_ema (deferred fix-up)");
+  return CQLREC_OK;
+}
+
 extern "C" int cqlrec_adam_ema(float* theta, float* grads, float* m, float* v, float* target, uint16_t* theta_b,
                                uint16_t* target_b, int64_t n, float step_size, float sqrt_bc2, float beta1, float beta2,
                                float eps, float tau, int32_t zero_grads, cqlrec_stream stream) {

@@ -915,7 +915,8 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
                                int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
                                float scale, void* ws, int64_t ws_bytes, float* g_E_out, float* g_b_out,
                                cqlrec_stream stream, bool sparse_first, bool do_sparse = true, int64_t item_lo = 0,
-                               int64_t item_hi = -1) {
+                               int64_t item_hi = -1, CqlAdamFix* defer = nullptr) {
+  if (defer) defer->valid = 0;
   if (item_hi < 0) item_hi = n_items;
   CQL_REQUIRE(item_lo >= 0 && item_lo < item_hi && item_hi <= n_items, "qhead_bwd_items: bad item range");
   CQL_REQUIRE(H_b && nlse2 && coef && act && E_out_b && b_out && ws && g_E_out && g_b_out, "qhead_bwd_items: NULL pointer");
@@ -977,7 +978,8 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
   static const bool use_qde = !(getenv("CQL_QDE") && getenv("CQL_QDE")[0] == '0');
   if (use_qde) {
     const int rc = cql_qde_launch(H_b, nlse2, batch, E_out_b + item_lo * d, b_out + item_lo, item_hi - item_lo, d, scale,
-                                  ws, ws_bytes, g_E_out + item_lo * d, g_b_out + item_lo, sparse_first ? 1 : 0, s);
+                                  ws, ws_bytes, g_E_out + item_lo * d, g_b_out + item_lo, sparse_first ? 1 : 0, s,
+                                  (item_lo == 0 && item_hi == n_items) ? defer : nullptr);
     if (rc != CQLREC_OK) return rc;
   } else {
     const int64_t rblks_all = (n_items + 127) / 128;
@@ -1073,9 +1075,9 @@ extern "C" int cqlrec_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_it
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,
-                            int64_t item_lo, int64_t item_hi) {
+                            int64_t item_lo, int64_t item_hi, CqlAdamFix* defer) {
   return qhead_bwd_items_impl(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
-                              g_b_out, (cqlrec_stream)stream, true, do_sparse != 0, item_lo, item_hi);
+                              g_b_out, (cqlrec_stream)stream, true, do_sparse != 0, item_lo, item_hi, defer);
 }
 
 extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,

@@ -397,7 +397,8 @@ static void qde_fixup_d(const QDeArgs& a, int grid, int waves, hipStream_t s) {
 // g_E_out / g_b_out rows [0, n_items) of this call: out (+)= scale * dE (accumulate: on top of what is there)
 int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const uint16_t* E_b, const float* bias,
                    int64_t n_items, int32_t d, float scale, void* ws, int64_t ws_bytes, float* out, float* out_cs,
-                   int accumulate, hipStream_t s) {
+                   int accumulate, hipStream_t s, CqlAdamFix* defer) {
+  if (defer) defer->valid = 0;
   CQL_REQUIRE(ws_bytes >= cql_qde_ws_bytes(batch, n_items, d), "qde: workspace too small");
   CQL_REQUIRE(batch * 2 * d < (1ll << 31), "qde: batch=%lld too large for one buffer descriptor", (long long)batch);
   const bool form2 = de_form2(d, batch);
@@ -442,7 +443,18 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
   const int64_t W = (int64_t)a.G * a.T;
   bool cut = false;                    // does some range start inside a group?
   for (int p = 1; p < grid && !cut; ++p) cut = ((int64_t)p * W / grid) % a.T != 0;
-  if (cut) {
+  if (cut && defer) {     // the consumer of the gradient adds the slabs (see CqlAdamFix): same terms, same order
+    defer->valid = 1;
+    defer->slab = a.slab;
+    defer->slab_cs = a.slab_cs;
+    defer->G = a.G;
+    defer->T = a.T;
+    defer->nblk = grid;
+    defer->items = items;
+    defer->D = d;
+    defer->scale = a.scale;
+    defer->n_items = n_items;
+  } else if (cut) {
     CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     if (d == 64) qde_fixup_d<64>(a, grid, waves, s);
     else if (d == 128) qde_fixup_d<128>(a, grid, waves, s);

@@ -78,14 +78,14 @@ int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,
-                            int64_t item_lo, int64_t item_hi);
+                            int64_t item_lo, int64_t item_hi, CqlAdamFix* defer = nullptr);
 
 
 // qhead_de.hip: the item-side backward as a persistent, statically balanced kernel (rows [0, n_items) of E_b / bias / out)
 int64_t cql_qde_ws_bytes(int64_t batch, int64_t n_items, int32_t d);
 int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const uint16_t* E_b, const float* bias,
                    int64_t n_items, int32_t d, float scale, void* ws, int64_t ws_bytes, float* out, float* out_cs,
-                   int accumulate, hipStream_t s);
+                   int accumulate, hipStream_t s, CqlAdamFix* defer = nullptr);
 
 // qhead_topk2.hip: the top-K pass as a one-wave-per-SIMD kernel with on-chip selection (d = 128, k <= 16, whole catalogue)
 struct QTk2Args {

@@ -159,7 +159,7 @@ struct SideStream {
   hipStream_t s3 = nullptr;   // sampling + sorts of the NEXT step (cqlrec_train_steps)
   hipEvent_t sorted[2] = {nullptr, nullptr};   // sorted pairs of the step with this parity are in place
   hipEvent_t forked = nullptr, fork2 = nullptr, join2 = nullptr;
-  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr;
+  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr;
   bool ok = false;
   bool tried = false;
 };
@@ -190,7 +190,8 @@ SideStream& side_stream() {
             hipEventCreateWithFlags(&ss.items, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.dh, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.eout, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.presample, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ss.presample, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.adam_in, hipEventDisableTiming) == hipSuccess;
   }
   return ss;
 }
@@ -321,7 +322,7 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
 }
 
 // item-side backward.  ctx->grads is zero on entry (contract of the step).
-int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, CqlAdamFix* defer = nullptr) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d;
   StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
@@ -336,7 +337,7 @@ int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
                              (hipStream_t)stream));
   return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, alpha_scale(c),
                                  w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
-                                 (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1);
+                                 (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1, defer);
 }
 
 // records `dh` behind dh_finish, the last reader of the E_out shadow on this stream: the item-side Adam waits for it
@@ -425,6 +426,8 @@ extern "C" int cqlrec_train_step_fwd_bwd(const cqlrec_train_ctx* c, uint64_t ste
 //     it runs under the MFMA-bound item-side kernel -- then ALREADY the prologue of step t+1 (sample, window gathers,
 //     encoder: they read only E_in / W), which waits for the item-side Adam only in front of its Q-head kernels.
 // Same dataflow as fwd_bwd + update per step; joined before returning.  world must be 1 (no all-reduce in here).
+int update_range_impl(const cqlrec_train_ctx* c, uint64_t step, int64_t lo, int64_t hi, cqlrec_stream stream,
+                      const CqlAdamFix* fix);
 extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int32_t n_steps, float* loss_out,
                                   cqlrec_stream stream) {
   CQL_TRY(check_ctx(c));
@@ -454,19 +457,32 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
         sampled = ss.presample;
       }
       CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.loss, 0), "train_steps");
-      CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s));          // sparse scatter, then the long dE_out kernel
+      // sparse scatter, then the long dE_out kernel; the sum of its cut pieces is left to the item-side Adam below
+      static const int defer_fixup = !(getenv("CQL_DEFER_FIXUP") && getenv("CQL_DEFER_FIXUP")[0] == '0');
+      CqlAdamFix fix = {};
+      CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s, defer_fixup ? &fix : nullptr));
       if (g_mark_phase == 1) mark(MK_DE, ss.s);
       CQL_TRY(backward_states_impl(c, step, stream));                      // dh_finish, records ss.dh
       if (g_mark_phase == 1) mark(MK_DH, s);
-      CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.dh, 0), "train_steps");     // dh_finish reads the E_out shadow
-      CQL_TRY(cqlrec_train_step_update_range(c, step, L.off_E_out, L.off_W1, (cqlrec_stream)ss.s));
-      CQL_HIP_TRY(hipEventRecord(ss.eout, ss.s), "train_steps");
-      if (g_mark_phase == 1) mark(MK_ADAM_OUT, ss.s);
       CQL_TRY(backward_chain_impl(c, step, stream));                       // encoder, window gather
       if (g_mark_phase == 1) mark(MK_CHAIN, s);
       CQL_TRY(cqlrec_train_step_update_range(c, step, L.off_W1, L.total, stream));
       CQL_TRY(cqlrec_train_step_update_range(c, step, 0, L.off_E_out, stream));
-      if (g_mark_phase == 1) { mark(MK_ADAM_IN, s); g_mark_phase = 2; }
+      if (g_mark_phase == 1) mark(MK_ADAM_IN, s);
+      // The two Adam launches are HBM-bound and ready at about the same time.  Side by side each takes twice as long
+      // and the next prologue (which needs E_in / W only) starts behind both; one after the other -- state side first --
+      // the prologue runs under the item-side Adam, and the next Q-head pass waits for that one alone.
+      static const int adam_serial = !(getenv("CQL_ADAM_SERIAL") && getenv("CQL_ADAM_SERIAL")[0] == '0');
+      if (adam_serial) {
+        CQL_HIP_TRY(hipEventRecord(ss.adam_in, s), "train_steps");
+        CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.adam_in, 0), "train_steps");
+      }
+      CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.dh, 0), "train_steps");     // dh_finish reads the E_out shadow
+      fix.rows_off = 0;
+      fix.cs_off = L.off_b_out - L.off_E_out;
+      CQL_TRY(update_range_impl(c, step, L.off_E_out, L.off_W1, (cqlrec_stream)ss.s, &fix));
+      CQL_HIP_TRY(hipEventRecord(ss.eout, ss.s), "train_steps");
+      if (g_mark_phase == 1) { mark(MK_ADAM_OUT, ss.s); g_mark_phase = 2; }
       pending = ss.eout;
     } else {
       CQL_TRY(backward_rest_impl(c, step, stream));
@@ -482,6 +498,11 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
 // Adam + target + shadows (+ zero grads) over elements [lo, hi) of the flat buffers (multiples of 4)
 extern "C" int cqlrec_train_step_update_range(const cqlrec_train_ctx* c, uint64_t step, int64_t lo, int64_t hi,
                                               cqlrec_stream stream) {
+  return update_range_impl(c, step, lo, hi, stream, nullptr);
+}
+
+int update_range_impl(const cqlrec_train_ctx* c, uint64_t step, int64_t lo, int64_t hi, cqlrec_stream stream,
+                      const CqlAdamFix* fix) {
   CQL_TRY(check_ctx(c));
   CQL_REQUIRE(lo >= 0 && hi <= c->layout.total && lo < hi && lo % 4 == 0 && hi % 4 == 0,
               "train_step_update_range: bad range [%lld, %lld)", (long long)lo, (long long)hi);
@@ -490,9 +511,9 @@ extern "C" int cqlrec_train_step_update_range(const cqlrec_train_ctx* c, uint64_
   const double bc2 = 1.0 - pow((double)c->beta2, t);
   const float step_size = (float)((double)c->lr / bc1);
   const float sqrt_bc2 = (float)sqrt(bc2);
-  return cqlrec_adam_ema(c->theta + lo, c->grads + lo, c->adam_m + lo, c->adam_v + lo, c->target + lo, c->theta_b + lo,
-                         c->target_b + lo, hi - lo, step_size, sqrt_bc2, (float)c->beta1, (float)c->beta2, (float)c->eps, (float)c->tau, 1,
-                         stream);
+  return cql_adam_ema_fix(c->theta + lo, c->grads + lo, c->adam_m + lo, c->adam_v + lo, c->target + lo, c->theta_b + lo,
+                          c->target_b + lo, hi - lo, step_size, sqrt_bc2, (float)c->beta1, (float)c->beta2, (float)c->eps,
+                          (float)c->tau, 1, fix, (hipStream_t)stream);
 }
 
 extern "C" int cqlrec_train_step_update(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
