@@ -104,6 +104,9 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
   constexpr int VPS = C::LPS + 1;            // vmcnt units per stage per wave (tile pieces + scalar strip)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object of this kernel
 
+  if constexpr (MODE == QM_LSE_DH) {     // fall-back launch behind qfwd2_kernel: runs only when that kernel asked for it
+    if (a.guard && __builtin_nontemporal_load(a.guard) == 0) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -601,11 +604,19 @@ static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
   return 0;
 }
 
+static int qs_launch_switch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
   static const int phase_of[8] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
                                   CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE, CQLREC_PH_QHEAD_LSE,
                                   CQLREC_PH_TOPK_TILEMAX};
   CqlProfScope prof(phase_of[mode], s);
+  return qs_launch_switch(mode, a, d, rblks, s);
+}
+// without a measurement scope of its own (the caller brackets it)
+static int qs_launch_quiet(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
+  return qs_launch_switch(mode, a, d, rblks, s);
+}
+static int qs_launch_switch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
   switch (mode) {
     case QM_LSE:
       if (qs_spw_fwd(d) == 4) return qs_launch_mode<QM_LSE, 4>(a, d, rblks, s);
@@ -1002,6 +1013,7 @@ extern "C" int cqlrec_qhead_bwd_items(const uint16_t* H_b, const float* nlse2, c
 struct FusedWs {
   QSplit sp;
   float *slab, *part_a, *part_b;
+  int* flag;          // qfwd2_kernel: "a partial sum overflowed, redo the pass with the first form"
   int64_t bytes;
 };
 static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
@@ -1011,7 +1023,8 @@ static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
   f.slab = (float*)ws;
   f.part_a = (float*)((char*)ws + slab_b);
   f.part_b = (float*)((char*)ws + slab_b + seg);
-  f.bytes = slab_b + 2 * seg;
+  f.flag = (int*)((char*)ws + slab_b + 2 * seg);
+  f.bytes = slab_b + 2 * seg + 256;
   return f;
 }
 
@@ -1034,7 +1047,36 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
   a.part_a = f.part_a;
   a.part_b = f.part_b;
   a.tg = 1;
-  qs_launch(QM_LSE_DH, a, d, f.sp.rblks, s);
+  if (cql_qfwd2_supported(d, n_items)) {
+    // one wave per SIMD, fixed per-slice reference (qhead_fwd2.hip); the first form follows, guarded by the flag the
+    // second sets when a partial sum overflowed -- its blocks return at once otherwise
+    if (hipMemsetAsync(f.flag, 0, 4, s) != hipSuccess) {
+      cql_set_error("qhead_fwd_lse_dh: hipMemsetAsync failed");
+      return CQLREC_ERR_HIP;
+    }
+    QFwd2Args a2 = {};
+    a2.H_b = H_b;
+    a2.n_states = rows;
+    a2.E_b = E_out_b;
+    a2.bias = b_out;
+    a2.n_items = n_items;
+    a2.nsplit = f.sp.nsplit;
+    a2.split_rows = f.sp.split_rows;
+    a2.slab = f.slab;
+    a2.part_a = f.part_a;
+    a2.part_b = f.part_b;
+    a2.flag = f.flag;
+    {
+      CqlProfScope prof(CQLREC_PH_QHEAD_LSE, s);
+      const int rc = cql_qfwd2_run(a2, d, s);
+      if (rc != CQLREC_OK) return rc;
+    }
+    a.guard = f.flag;
+    CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+    qs_launch_quiet(QM_LSE_DH, a, d, f.sp.rblks, s);
+  } else {
+    qs_launch(QM_LSE_DH, a, d, f.sp.rblks, s);
+  }
   CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
   hipLaunchKernelGGL(qhead_finalize_lse_kernel, dim3(cql_ceil_div(rows, 256)), dim3(256), 0, s, a.part_a, a.part_b,
                      a.nsplit, rows, out_lse, out_nlse2);

@@ -48,6 +48,7 @@ struct QArgs {
   int accumulate;            // direct output adds to out / out_cs instead of overwriting (rows are block-owned: no atomics)
   // QM_TOPK: per (slice, user, lane half) the QS_TOPK_K best admissible candidates as sortable 64-bit keys
   // (order-preserving score bits << 32 | ~candidate row), best first, 0 = none
+  const int* guard;                // QM_LSE_DH as a fall-back launch: every block returns at once unless *guard != 0
   unsigned long long* topk_keys;   // [nsplit][n_res][2][QS_TOPK_K]
   int topk_k;                      // requested k (<= QS_TOPK_K): the pruning threshold is the k-th best so far
   const uint32_t* seen_bits;       // [n_res][seen_w] bitmap of the rows to exclude per owner row (NULL: no filter)
@@ -106,3 +107,20 @@ int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand);
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
                         int64_t n_cand, uint32_t* bits, hipStream_t s);
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
+
+// qhead_fwd2.hip: the fused forward (lse + softmax-weighted item sum) as a one-wave-per-SIMD kernel (d = 128)
+struct QFwd2Args {
+  const uint16_t* H_b;      // [n_states x D] owner rows
+  int64_t n_states;
+  const uint16_t* E_b;      // [n_items x D] streamed rows
+  const float* bias;        // [n_items]
+  int64_t n_items;
+  int nsplit;
+  int64_t split_rows;       // items per slice (multiple of 64)
+  float* slab;              // [nsplit][n_states][D]
+  float* part_a;            // [nsplit][n_states] reference (natural units)
+  float* part_b;            // [nsplit][n_states] sum of exp(S - reference)
+  int* flag;                // set when a partial sum is not finite (the guarded first form then redoes the pass)
+};
+bool cql_qfwd2_supported(int d, int64_t n_items);
+int cql_qfwd2_run(const QFwd2Args& a, int d, hipStream_t s);
