@@ -23,6 +23,23 @@
 
 #define QF2_REF_MARGIN 8.0f
 
+// Y += A . B with the accumulator in AccVGPRs, as inline asm: the builtin form of this translation unit
+// (-amdgpu-mfma-vgpr-form, which the score chains need: the VALU reads their results) would put the 128 accumulator
+// registers of Y into the VGPR half too, and the rest of the kernel then no longer fits there -- hipcc parks owner
+// fragments in AccVGPRs and copies them back in front of every product.  A = transposed item fragment (VGPRs: where
+// hipcc lets the ds_read_tr land), B = probability fragment (VGPRs).  The leading s_nop covers "VALU wrote B just before"
+// (the hazard recogniser does not look into asm); products on the same accumulator are four products apart.
+#ifndef QF2_BUILTIN_Y
+__device__ __forceinline__ void qf2_mfma_y(f32x16& y, const bf16x8& a_frag, const bf16x8& b_frag) {
+  const u32x4 av = __builtin_bit_cast(u32x4, a_frag), bv = __builtin_bit_cast(u32x4, b_frag);
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(y) : "v"(av), "v"(bv));
+}
+#else
+__device__ __forceinline__ void qf2_mfma_y(f32x16& y, const bf16x8& a_frag, const bf16x8& b_frag) {
+  y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_frag, b_frag, y, 0, 0, 0);
+}
+#endif
+
 template <int D>
 __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
   using C = DeCfg<D, 4>;
@@ -126,6 +143,9 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
                             // copying them back in front of every product
   bf16x8 tf[2][FT][2];
   bf16x8 dpa, dpb;
+  // half-chunks of the exponentials (qde2_kernel's; volatile asm: hipcc would otherwise regroup them).  Packed forms
+  // (v_pk_fma_f32 for both exponent arguments, v_pk_add_f32 into a pair of partial sums: 5 instead of 7 instructions per
+  // pair) were measured: slower (0.270 vs 0.200 ms) -- the packed fp32 instructions are not full rate here.
   float ht0 = 0.f, ht1 = 0.f;
   auto half_a = [&](const f32x16& acc, int k, float b0) __attribute__((always_inline)) {
     asm volatile(
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
     for (int gp = 0; gp < 32; ++gp) {
       if (gp < 5) {
         const int m = 3 + gp, ft = m % FT, s2 = m / FT;
-        y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P ^ 1][ft][s2], s2 ? dpb : dpa, y[1][ft], 0, 0, 0);
+        qf2_mfma_y(y[1][ft], tf[P ^ 1][ft][s2], s2 ? dpb : dpa);
       } else if (gp < 13) {
         const int s = gp - 5;
         if (s == 0) acc1 = sv;
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
         const int m = gp - 13, ft = m % FT, s2 = m / FT;
         if (m == 0) pa0 = frag(pw0, 0);
         if (m == FT) pb0 = frag(pw0, 1);
-        y[0][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P][ft][s2], s2 ? pb0 : pa0, y[0][ft], 0, 0, 0);
+        qf2_mfma_y(y[0][ft], tf[P][ft][s2], s2 ? pb0 : pa0);
       } else if (gp < 29) {
         const int s = gp - 21;
         if (s == 0) acc0 = sv;
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
       } else {
         const int m = gp - 29, ft = m % FT;
         if (m == 0) pa1 = frag(pw1, 0);
-        y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[P][ft][0], pa1, y[1][ft], 0, 0, 0);
+        qf2_mfma_y(y[1][ft], tf[P][ft][0], pa1);
       }
       QF2_FENCE();
       {
@@ -312,8 +332,9 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
 #pragma unroll
   for (int m = 3; m < 2 * FT; ++m) {
     const int ft = m % FT, s2 = m / FT;
-    y[1][ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][ft][s2], s2 ? dpb : dpa, y[1][ft], 0, 0, 0);
+    qf2_mfma_y(y[1][ft], tf[1][ft][s2], s2 ? dpb : dpa);
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last products have left the pipe before Y is read
 
   // ---- partials: (reference, sum relative to it) and the un-normalised slab -----------------------------------------
 #pragma unroll
