@@ -288,25 +288,27 @@ def main():
     # ---- top-K scoring pass (second half of the metric) --------------------------------------------------------
     topk = None
     if not args.no_topk:
-        nu = min(cfg["topk_users"], hi - lo)
+        # all users of this rank's shard, in chunks of cfg["topk_users"] (one launch of the scoring kernel each)
+        nu = hi - lo
+        tk_chunk = min(cfg["topk_users"], nu)
         users = torch.arange(nu, dtype=torch.int32, device=dev)
         # seen lists = items sorted inside each user's row (input preparation, untimed)
         rows = torch.repeat_interleave(torch.arange(hi - lo, device=dev), off[1:] - off[:-1])
         seen_items = items[torch.argsort(rows * NI + items.to(torch.int64))].contiguous()
         del rows
-        core.encode_topk(off, items, users[:1024], K, seen=(off, seen_items), chunk=nu)      # warm-up
+        core.encode_topk(off, items, users[:1024], K, seen=(off, seen_items), chunk=tk_chunk)      # warm-up
         barrier()
         t1 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            idx, val, cnt = core.encode_topk(off, items, users, K, seen=(off, seen_items), chunk=nu)
+            idx, val, cnt = core.encode_topk(off, items, users, K, seen=(off, seen_items), chunk=tk_chunk)
         barrier()
         dtk = time.perf_counter() - t1
         # per-kernel durations from one more, event-bracketed pass (not part of `value`: the brackets cost ~8 % here)
         tk_ph = {}
         if not args.no_prof:
             N.check(lib.cqlrec_prof_enable(1), "prof_enable")
-            core.encode_topk(off, items, users, K, seen=(off, seen_items), chunk=nu)
+            core.encode_topk(off, items, users, K, seen=(off, seen_items), chunk=tk_chunk)
             barrier()
             tk_ph = N.prof_read()
             N.check(lib.cqlrec_prof_enable(0), "prof_enable")
@@ -335,10 +337,12 @@ def main():
         if tk_ph.get("gather_fwd", (0, 0))[1]:
             # the window gather at a size that fills the chip: one launch over all `nu` users of the scoring pass
             # (the training step's gathers cover only B = 4096 states and are launch/latency bound)
-            g_ms = tk_ph["gather_fwd"][0] / tk_ph["gather_fwd"][1]
+            g_n = tk_ph["gather_fwd"][1]
+            g_ms = tk_ph["gather_fwd"][0] / g_n
             lens_u = (off[1: nu + 1] - off[:nu]).clamp(max=L).float().mean().item()
-            gb = nu * (lens_u * d * 2 + lens_u * 4) + nu * d * 2        # rows + indices in, bf16 state out
-            topk["roofline_gather"] = hbm_roofline(gb, g_ms, table_bytes=NI * d * 2, states_per_launch=nu)
+            gb = (nu * (lens_u * d * 2 + lens_u * 4) + nu * d * 2) / g_n      # rows + indices in, bf16 state out, per launch
+            topk["roofline_gather"] = hbm_roofline(gb, g_ms, table_bytes=NI * d * 2, states_per_launch=nu // g_n,
+                                                   note="runs on the side stream beside the scoring kernel of the previous chunk")
 
     if rank != 0:
         if world > 1:

@@ -210,6 +210,8 @@ int cqlrec_score_topk(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b,
 #define CQLREC_TOPK_ALL 0
 #define CQLREC_TOPK_SEEN 1
 #define CQLREC_TOPK_SCORE 2
+#define CQLREC_TOPK_SEEN_BESIDE 3 /* = _SEEN, launched while a _SCORE phase of another workspace runs on another stream:
+                                     the builder then uses what that kernel leaves free of a CU (small LDS tiles) */
 int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b, int64_t n_cand,
                             int32_t d, const int32_t* item_ids, const int64_t* seen_off, const int32_t* seen_items,
                             const int32_t* seen_rows, int32_t k, void* ws, int64_t ws_bytes, int32_t* out_idx,

@@ -15,7 +15,7 @@ _LIB_PATH = Path(os.environ["CQLREC_LIB"]).resolve() if os.environ.get("CQLREC_L
 _lib: Optional[C.CDLL] = None
 
 ABI_VERSION = 2
-TOPK_ALL, TOPK_SEEN, TOPK_SCORE = 0, 1, 2
+TOPK_ALL, TOPK_SEEN, TOPK_SCORE, TOPK_SEEN_BESIDE = 0, 1, 2, 3
 QHEAD_LSE = 1
 QHEAD_ARGMAX = 2
 

@@ -510,34 +510,52 @@ class CQLCore:
         if seen is not None:    # the seen bitmap of a chunk (users x items bits) stays under 4 GiB
             chunk = min(chunk, max(4096, int((4 << 30) // max(1, n_cand // 8)) // 256 * 256))
         ws_bytes = int(self.lib.cqlrec_topk_ws_bytes(chunk, n_cand, h.d, k))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         main = torch.cuda.current_stream()
         s = main.cuda_stream
         hb_fn = hb if callable(hb) else None
-        if hb_fn is not None and self._topk_side is None:
-            self._topk_side = torch.cuda.Stream(device=self.device)
-        for lo in range(0, n, chunk):
-            hi = min(n, lo + chunk)
-            rows_ptr = None if seen_rows is None else seen_rows.data_ptr() + 4 * lo
+        n_chunks = (n + chunk - 1) // chunk
 
-            def call(hptr, phase, stream):
-                N.check(self.lib.cqlrec_score_topk_phase(
-                    hptr, hi - lo, E_ptr, b_ptr, n_cand, h.d, ids_ptr,
-                    None if seen is None else _ptr(seen[0]), None if seen is None else _ptr(seen[1]), rows_ptr, k,
-                    _ptr(ws), ws_bytes, out_idx.data_ptr() + 4 * k * lo, out_val.data_ptr() + 4 * k * lo,
-                    out_cnt.data_ptr() + 4 * lo, phase, stream), "score_topk")
-            if hb_fn is None:
-                call(hb.data_ptr() + 2 * h.d * lo, N.TOPK_ALL, s)
-            else:
-                # the seen bitmap of the chunk does not depend on the state vectors: it is built on a side stream
-                # while the encoder runs on this one
-                side = self._topk_side
-                side.wait_stream(main)          # (the previous chunk's scoring reads the same workspace)
-                call(None, N.TOPK_SEEN, side.cuda_stream)
-                hb_c = hb_fn(lo, hi)
-                main.wait_stream(side)
-                call(hb_c.data_ptr(), N.TOPK_SCORE, s)
+        def call(ws_, lo, hi, hptr, phase, stream):
+            rows_ptr = None if seen_rows is None else seen_rows.data_ptr() + 4 * lo
+            N.check(self.lib.cqlrec_score_topk_phase(
+                hptr, hi - lo, E_ptr, b_ptr, n_cand, h.d, ids_ptr,
+                None if seen is None else _ptr(seen[0]), None if seen is None else _ptr(seen[1]), rows_ptr, k,
+                _ptr(ws_), ws_bytes, out_idx.data_ptr() + 4 * k * lo, out_val.data_ptr() + 4 * k * lo,
+                out_cnt.data_ptr() + 4 * lo, phase, stream), "score_topk")
+        if hb_fn is None:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            for lo in range(0, n, chunk):
+                hi = min(n, lo + chunk)
+                call(ws, lo, hi, hb.data_ptr() + 2 * h.d * lo, N.TOPK_ALL, s)
+        else:
+            # Software pipeline over the chunks: what a chunk needs before it can be scored -- its seen bitmap (depends
+            # on the lists only) and its state vectors (window gather + encoder) -- is HBM-bound work and runs on a
+            # side stream under the MFMA-bound scoring kernel of the chunk before; two workspaces alternate.
+            if self._topk_side is None:
+                self._topk_side = torch.cuda.Stream(device=self.device)
+            side = self._topk_side
+            wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) for _ in range(min(2, n_chunks))]
+            scored = [torch.cuda.Event() for _ in range(n_chunks)]
+            side.wait_stream(main)
+            for i, lo in enumerate(range(0, n, chunk)):
+                hi = min(n, lo + chunk)
+                ws_ = wss[i % 2]
+                with torch.cuda.stream(side):
+                    if i >= 2:
+                        side.wait_event(scored[i - 2])          # the workspace is free again
+                    call(ws_, lo, hi, None, N.TOPK_SEEN if i == 0 else N.TOPK_SEEN_BESIDE, side.cuda_stream)
+                    if i > 0:
+                        hb_c = hb_fn(lo, hi)
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                if i == 0:          # nothing is being scored yet: the first chunk is encoded beside its bitmap
+                    hb_c = hb_fn(lo, hi)
+                main.wait_event(ready)
+                call(ws_, lo, hi, hb_c.data_ptr(), N.TOPK_SCORE, s)
+                scored[i].record(main)
                 hb_c.record_stream(main)
+            for w_ in wss:
+                w_.record_stream(side)
         del keep
         return out_idx, out_val, out_cnt
 
@@ -547,8 +565,8 @@ class CQLCore:
                     cand_items: Optional[torch.Tensor] = None,
                     seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
                     chunk: int = 65536) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """encode(offsets, items, users) + score_topk in one pipelined pass (the predict path, S7): per chunk of users the
-        seen bitmap is built on a side stream while the window gather and the encoder run."""
+        """encode(offsets, items, users) + score_topk in one pipelined pass (the predict path, S7): the seen bitmap and
+        the state vectors of chunk i+1 are produced on a side stream while chunk i is scored."""
         if seen is not None and seen_rows is None:
             seen_rows = users.to(device=self.device, dtype=torch.int32)
         if k > self.MAX_FUSED_K:

@@ -105,7 +105,7 @@ bool cql_topk2_supported(int d, int k, int64_t n_cand);
 void cql_topk2_split(int64_t n_users, int64_t n_cand, int* nsplit, int64_t* split_rows);
 int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand);
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
-                        int64_t n_cand, uint32_t* bits, hipStream_t s);
+                        int64_t n_cand, uint32_t* bits, hipStream_t s, int beside_scoring = 0);
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
 
 // qhead_fwd2.hip: the fused forward (lse + softmax-weighted item sum) as a one-wave-per-SIMD kernel (d = 128)

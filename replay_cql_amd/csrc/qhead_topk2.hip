@@ -440,7 +440,10 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
 // (memset + atomicOr per entry took 0.30 ms for 65536 users x 100 000 items; the bitmap alone is 0.13 ms of writes).
 // The lists are ASCENDING (cqlrec.h): four threads per user walk a list with one cursor per user.
 // =============================================================================================================
-#define TK2_BCH 96      // stages per LDS tile: 96 x 512 B = 48 KiB
+// BCH = stages per LDS tile (512 B each): 96 (48 KiB) when the builder has the chip to itself; 12 (6 KiB) when it runs on
+// a side stream beside qtopk2_kernel, whose block leaves 7 KiB of a CU's LDS free -- with the large tile no block of the
+// builder becomes resident before the scoring kernel has finished.
+template <int TK2_BCH>
 __global__ __launch_bounds__(256) void topk2_seen_bits_kernel(const int64_t* __restrict__ seen_off,
                                                               const int32_t* __restrict__ seen_items,
                                                               const int32_t* __restrict__ seen_rows, int64_t n_users,
@@ -521,9 +524,13 @@ int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand) {
 }
 
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
-                        int64_t n_cand, uint32_t* bits, hipStream_t s) {
-  hipLaunchKernelGGL(topk2_seen_bits_kernel, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off, seen_items,
-                     seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits);
+                        int64_t n_cand, uint32_t* bits, hipStream_t s, int beside_scoring) {
+  if (beside_scoring)
+    hipLaunchKernelGGL(topk2_seen_bits_kernel<12>, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off,
+                       seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits);
+  else
+    hipLaunchKernelGGL(topk2_seen_bits_kernel<96>, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off,
+                       seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits);
   CQL_LAUNCH_CHECK("topk2_seen_bits");
   return CQLREC_OK;
 }

@@ -692,9 +692,9 @@ extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, con
                                        const int32_t* seen_items, const int32_t* seen_rows, int32_t k, void* ws,
                                        int64_t ws_bytes, int32_t* out_idx, float* out_val, int32_t* out_cnt,
                                        int32_t phase, cqlrec_stream stream) {
-  CQL_REQUIRE(phase == CQLREC_TOPK_ALL || phase == CQLREC_TOPK_SEEN || phase == CQLREC_TOPK_SCORE,
-              "score_topk: phase=%d", phase);
-  if (phase == CQLREC_TOPK_SEEN) {     // the part that does not depend on the state vectors
+  CQL_REQUIRE(phase == CQLREC_TOPK_ALL || phase == CQLREC_TOPK_SEEN || phase == CQLREC_TOPK_SCORE ||
+                  phase == CQLREC_TOPK_SEEN_BESIDE, "score_topk: phase=%d", phase);
+  if (phase == CQLREC_TOPK_SEEN || phase == CQLREC_TOPK_SEEN_BESIDE) {     // the part that does not depend on the state vectors
     CQL_REQUIRE(ws && n_users > 0 && n_cand > 0, "score_topk (seen phase): bad arguments");
     CQL_REQUIRE(ws_bytes >= cqlrec_topk_ws_bytes(n_users, n_cand, d, k), "score_topk: workspace too small");
     if (!seen_off || !tk_uses_topk2(d, k, n_cand, item_ids)) return CQLREC_OK;   // other forms filter while they select
@@ -704,7 +704,8 @@ extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, con
     cql_topk2_split(n_users, n_cand, &ns, &sr);
     uint32_t* bits = (uint32_t*)((char*)ws + align256((int64_t)ns * n_users * 2 * QS_TOPK_K * 8));
     CqlProfScope prof(CQLREC_PH_TOPK_SELECT, (hipStream_t)stream);
-    return cql_topk2_seen_bits(seen_off, seen_items, seen_rows, n_users, n_cand, bits, (hipStream_t)stream);
+    return cql_topk2_seen_bits(seen_off, seen_items, seen_rows, n_users, n_cand, bits, (hipStream_t)stream,
+                               phase == CQLREC_TOPK_SEEN_BESIDE);
   }
   CQL_REQUIRE(H_b && E_b && b && ws && out_idx && out_val && out_cnt, "score_topk: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "score_topk: d=%d unsupported", d);
