@@ -382,7 +382,11 @@ def main():
         dom = max(qk, key=qk.get)
         flops = 2.0 * B * NI * d          # algorithmic flops of ONE Q-head GEMM (8*B*N*d per step = 4 GEMMs)
         ach = gemms[dom] * flops / (qk[dom] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": f"qstream_kernel<{dom}>", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
+        kname = {"qhead_lse": "qfwd2_kernel<128> (fused forward: lse + softmax-weighted item sum)" if d == 128
+                 else "qstream_kernel<QM_LSE_DH>",
+                 "qhead_bwd_de": ("qde2_kernel<128>" if (d == 128 and B % 64 == 0) else "qde_kernel") + " (item-side backward)",
+                 "qhead_argmax": "qstream_kernel<QM_ARGMAX>"}.get(dom, dom)
+        out["roofline"] = {"kernel": kname, "phase": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_ms": qk[dom],
                            "algorithmic_flops_per_launch": gemms[dom] * flops}
         # `traffic`: HBM bytes per launch from the PMC counters -- collected in separate rocprofv3 --pmc passes (they cannot
