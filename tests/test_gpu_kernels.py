@@ -370,6 +370,41 @@ def test_qhead_fused_forward_dh(lib, B, Nn, d, ramp):
     assert np.abs(got - dH_ref).max() < 4e-3 * np.abs(dH_ref).max()
 
 
+@pytest.mark.parametrize("B,Nn", [(128, 1000), (300, 4099)])
+def test_qhead_fused_forward_overflow_falls_back(lib, B, Nn):
+    """d = 128: qfwd2_kernel fixes its reference from the first tile of every item slice.  A bias step of +200 nats
+    behind the first tile makes exp(S - ref) overflow there; the kernel flags it and the guarded first form redoes the
+    pass -- the result must be the exact one all the same."""
+    d = 128
+    Hb, Eb, b = _qhead_inputs(B, Nn, d, False, B + Nn + 3)
+    Hb = O.bf16_round(Hb * 0.5)
+    b = b.astype(np.float32)
+    b[40:] += np.float32(200.0)
+    rng = np.random.default_rng(B + 9)
+    act = rng.integers(0, Nn, B).astype(np.int32)
+    coef = (rng.standard_normal(B) * 0.01).astype(np.float32)
+    scale = np.float32(1.0 / B)
+    Q = O.qvalues(Hb, Eb, b)
+    lse = O.logsumexp_rows(Q)
+    P = np.exp(Q.astype(np.float64) - lse[:, None])
+    dH_ref = scale * (P @ Eb.astype(np.float64)) + coef[:, None] * Eb[act]
+    nb = int(lib.cqlrec_qhead_fused_ws_bytes(B, Nn, d))
+    ws = ws_bytes_tensor(nb)
+    lse_d = torch.empty(B, dtype=torch.float32, device=DEV)
+    dH = torch.empty((B, d), dtype=torch.float32, device=DEV)
+    Eb_d = bf16_dev(Eb)
+    N.check(lib.cqlrec_qhead_fwd_lse_dh(ptr(bf16_dev(Hb)), B, ptr(Eb_d), ptr(dev(b)), Nn, d, ptr(ws), nb, ptr(lse_d),
+                                        None, stream()))
+    N.check(lib.cqlrec_qhead_dh_finish(ptr(ws), B, Nn, d, ptr(lse_d), ptr(dev(coef)), ptr(dev(act)), ptr(Eb_d),
+                                       float(scale), ptr(dH), stream()))
+    sync()
+    assert np.isfinite(lse_d.cpu().numpy()).all()
+    np.testing.assert_allclose(lse_d.cpu().numpy(), lse, rtol=2e-6, atol=2e-5)
+    got = dH.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, dH_ref) < 3e-3
+
+
 # ------------------------------------------------------------------------------------------------ Adam
 def test_adam_bit_exact(lib):
     n = 64 * 1000
