@@ -830,15 +830,32 @@ extern "C" int64_t cqlrec_qhead_ws_bytes(int64_t rows, int64_t n_items, int32_t 
   return 3 * align256((int64_t)sp.nsplit * rows * 4) + 256;
 }
 
+static int qhead_fwd_impl(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                         int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx,
+                         float* out_nlse2, cqlrec_stream stream, bool small_waves);
 extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
                                 int64_t n_items, int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val,
                                 int32_t* out_idx, float* out_nlse2, cqlrec_stream stream) {
+  return qhead_fwd_impl(H_b, rows, E_out_b, b_out, n_items, d, mode, ws, ws_bytes, out_val, out_idx, out_nlse2, stream, false);
+}
+// ARGMAX with 32 states per wave and at most 128 registers (d = 128): slower on its own than the 64-state form, but its
+// waves fit beside qfwd2_kernel's on a SIMD (that kernel leaves 136 of the 512 registers per lane and 127 KiB of LDS), so
+// the step driver launches the two passes together and this one's MFMAs run in the issue gaps of the other.
+int cql_qhead_argmax_beside(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                            int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream) {
+  return qhead_fwd_impl(H_b, rows, E_out_b, b_out, n_items, d, CQLREC_QHEAD_ARGMAX, ws, ws_bytes, out_val, out_idx, nullptr,
+                        (cqlrec_stream)stream, d == 128);
+}
+static int qhead_fwd_impl(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                         int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx,
+                         float* out_nlse2, cqlrec_stream stream, bool small_waves) {
   CQL_REQUIRE(H_b && E_out_b && b_out && ws && out_val, "qhead_fwd: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_fwd: d=%d unsupported", d);
   CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
   CQL_REQUIRE(mode == CQLREC_QHEAD_LSE || mode == CQLREC_QHEAD_ARGMAX, "qhead_fwd: bad mode %d", mode);
   CQL_REQUIRE(ws_bytes >= cqlrec_qhead_ws_bytes(rows, n_items, d), "qhead_fwd: workspace too small");
-  const QSplit sp = qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI, QS_TARGET_BLOCKS);
+  const QSplit sp = small_waves ? qs_choose_split(n_items, rows, 1, QS_TI, 256)
+                                : qs_choose_split(n_items, rows, qs_spw_fwd(d), QS_TI, QS_TARGET_BLOCKS);
   const int64_t seg = align256((int64_t)sp.nsplit * rows * 4);
   QArgs a = {};
   a.res = H_b;
@@ -861,7 +878,12 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
     hipLaunchKernelGGL(qhead_finalize_lse_kernel, dim3(cql_ceil_div(rows, thr)), dim3(thr), 0, s, a.part_a, a.part_b,
                        a.nsplit, rows, out_val, out_nlse2);
   } else {
-    qs_launch(QM_ARGMAX, a, d, sp.rblks, s);
+    if (small_waves) {
+      CqlProfScope prof(CQLREC_PH_QHEAD_ARGMAX, s);
+      qs_launch_n<128, 1, QM_ARGMAX, QS_NBUF, 4>(a, sp.rblks, s);
+    } else {
+      qs_launch(QM_ARGMAX, a, d, sp.rblks, s);
+    }
     CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
     dim3 rg((unsigned)rows), rb(64);
 #define RES_AM(DD)                                                                                                \

@@ -108,6 +108,9 @@ int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, cons
                         int64_t n_cand, uint32_t* bits, hipStream_t s, int beside_scoring = 0);
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
 
+int cql_qhead_argmax_beside(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                            int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream);
+
 // qhead_fwd2.hip: the fused forward (lse + softmax-weighted item sum) as a one-wave-per-SIMD kernel (d = 128)
 struct QFwd2Args {
   const uint16_t* H_b;      // [n_states x D] owner rows

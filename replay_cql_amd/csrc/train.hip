@@ -159,7 +159,7 @@ struct SideStream {
   hipStream_t s3 = nullptr;   // sampling + sorts of the NEXT step (cqlrec_train_steps)
   hipEvent_t sorted[2] = {nullptr, nullptr};   // sorted pairs of the step with this parity are in place
   hipEvent_t forked = nullptr, fork2 = nullptr, join2 = nullptr;
-  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr;
+  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr, bpro = nullptr;
   bool ok = false;
   bool tried = false;
 };
@@ -191,7 +191,8 @@ SideStream& side_stream() {
             hipEventCreateWithFlags(&ss.dh, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.eout, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.presample, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.adam_in, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ss.adam_in, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.bpro, hipEventDisableTiming) == hipSuccess;
   }
   return ss;
 }
@@ -289,25 +290,45 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   cqlrec_stream sb = stream;
   const bool par = ss.ok && hipEventRecord(ss.fork2, s) == hipSuccess && hipStreamWaitEvent(ss.s2, ss.fork2, 0) == hipSuccess;
   if (par) sb = (cqlrec_stream)ss.s2;
+  // CQL_ARGMAX_CORUN=1 (d = 128; A/B knob, default off): the two catalogue passes are launched TOGETHER -- the ARGMAX pass
+  // in its small-wave form (cql_qhead_argmax_beside), whose waves fit beside the fused forward's on a SIMD -- with the
+  // prologue of branch B enqueued first and branch A waiting for it in front of its Q-head pass.  Measured: the step
+  // gets 3.5 % SLOWER (0.783 vs 0.757 ms): the fused forward is bound by instruction issue, not by the MFMA pipe, and a
+  // second wave on the SIMD takes issue slots from it.
+  static const bool corun_on = getenv("CQL_ARGMAX_CORUN") && getenv("CQL_ARGMAX_CORUN")[0] == '1';
+  const bool corun = par && d == 128 && corun_on;
+  auto branch_b_prologue = [&]() -> int {
+    CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, sb));
+    CQL_TRY(cqlrec_gather_pool_fwd(p.tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, sb));
+    CQL_TRY(cqlrec_linear_bf16(w.h0b + Bd, p.W1_b, p.b1, B, d, 1, nullptr, w.zb + Bd, sb));
+    CQL_TRY(cqlrec_linear_bf16(w.zb + Bd, p.W2_b, p.b2, B, d, 0, nullptr, w.hb + Bd, sb));
+    CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, sb));
+    CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, sb));
+    return CQLREC_OK;
+  };
+  if (corun) {
+    CQL_TRY(branch_b_prologue());
+    CQL_HIP_TRY(hipEventRecord(ss.bpro, ss.s2), "train_step_forward");
+  }
   // ---- branch A
   CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, w.h0_s, w.h0b, nullptr, stream));
   CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, B, d, 1, nullptr, w.zb, stream));
   CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, B, d, 0, nullptr, w.hb, stream));
   if (g_mark_phase == 2) mark(MK_PROLOGUE, s);
   if (eout_ready) CQL_HIP_TRY(hipStreamWaitEvent(s, eout_ready, 0), "train_step_forward");
+  if (corun) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.bpro, 0), "train_step_forward");
   // logsumexp AND the softmax-weighted sum of item rows (the soft part of dH) in ONE pass over the catalogue
   CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s));
   if (g_mark_phase == 2) mark(MK_LSE, s);
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
-  CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, sb));
-  CQL_TRY(cqlrec_gather_pool_fwd(p.tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, sb));
-  CQL_TRY(cqlrec_linear_bf16(w.h0b + Bd, p.W1_b, p.b1, B, d, 1, nullptr, w.zb + Bd, sb));
-  CQL_TRY(cqlrec_linear_bf16(w.zb + Bd, p.W2_b, p.b2, B, d, 0, nullptr, w.hb + Bd, sb));
-  CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, sb));
-  CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, sb));
+  if (!corun) CQL_TRY(branch_b_prologue());
   if (eout_ready && par) CQL_HIP_TRY(hipStreamWaitEvent(ss.s2, eout_ready, 0), "train_step_forward");
-  CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star, nullptr, sb));
+  if (corun)
+    CQL_TRY(cql_qhead_argmax_beside(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star,
+                                    (hipStream_t)sb));
+  else
+    CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star, nullptr, sb));
   CQL_TRY(cqlrec_gather_dot(w.hb_t, p.tEout_b, p.tb_out, w.a_star, B, d, w.q_targ, sb));
   if (par && (hipEventRecord(ss.join2, ss.s2) != hipSuccess || hipStreamWaitEvent(s, ss.join2, 0) != hipSuccess)) {
     cql_set_error("train_step_forward: joining the forward branches failed");
