@@ -202,3 +202,19 @@ def test_arrow_ingest_and_egress_on_cpu():
     assert rb.schema.equals(A.REC_SCHEMA)
     assert rb.to_pydict() == {"user_idx": [4, 4, 7, 7, 7], "item_idx": [9, 8, 1, 2, 3], "relevance": [0.5, 0.25, 3.0, 2.0, 1.0]}
     assert A.recs_to_arrow(users[:0], idx[:0], val[:0], torch.zeros(0, dtype=torch.int32)).num_rows == 0
+
+
+def test_bench_hbm_roofline_never_reports_more_than_the_peak():
+    """bench.hbm_roofline: frac is null for a table that fits the Infinity Cache (the algorithmic rate may exceed the HBM
+    peak there) and capped at 1 otherwise ('bench never prints frac > 1')."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("bench_mod", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    small = bench.hbm_roofline(alg_bytes=650e6, ms=0.066, table_bytes=25.6e6)           # 9.8 TB/s of cached rows
+    assert small["frac"] is None and small["infinity_cache_resident"] and small["achieved"] > bench.PEAK_HBM_GBS
+    big = bench.hbm_roofline(alg_bytes=3.47e9, ms=0.29, table_bytes=512e6)                # 12 TB/s algorithmic
+    assert big["frac"] == 1.0 and not big["infinity_cache_resident"]
+    adam = bench.hbm_roofline(alg_bytes=11.8e9, ms=2.43, table_bytes=5.4e9)
+    assert 0.55 < adam["frac"] < 0.65
