@@ -672,6 +672,9 @@ __device__ __forceinline__ void adam_fix4(const CqlAdamFix& f, float (&g)[4], in
   } else {
     return;
   }
+#ifdef ADAMFIX_ABL_NOLOOP      // timing-only build: the gradient without the slabs
+  return;
+#endif
   const uint32_t grp = item >> li, row = item & (uint32_t)(f.items - 1);
   const uint32_t W = (uint32_t)f.G * (uint32_t)f.T, nblk = (uint32_t)f.nblk, lo = grp * (uint32_t)f.T, hi = lo + (uint32_t)f.T;
   for (uint32_t p = ((lo + 1) * nblk + W - 1) / W; p < nblk; ++p) {     // the pieces, in block order

@@ -442,7 +442,8 @@ def test_adam_bit_exact(lib):
 # ------------------------------------------------------------------------------------------------ top-K
 @pytest.mark.parametrize("n_users,Nn,d,k", [(5, 40, 64, 10), (70, 1000, 128, 10), (130, 4099, 64, 25),
                                             (33, 10007, 128, 100), (20, 513, 256, 7), (9, 3000, 64, 700),
-                                            (6, 2500, 128, 2048)])
+                                            (6, 2500, 128, 2048), (300, 5000, 128, 16), (64, 2000, 128, 1),
+                                            (1000, 3000, 128, 5), (40, 70, 128, 16)])
 @pytest.mark.parametrize("with_seen", [False, True])
 def test_topk_dyadic_bit_exact(lib, n_users, Nn, d, k, with_seen):
     idx, val, cnt, idx_ref, val_ref, _ = _topk_case(lib, n_users, Nn, d, k, True, Nn + k, with_seen)
@@ -471,6 +472,40 @@ def test_topk_random_margin_rule(lib, with_seen):
     assert excluded <= 4
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_topk_heavy_seen_lists(lib, d):
+    """Users who have seen most of the catalogue, including ALL of their best items and everything but a handful (fewer
+    than k admissible items left for some): dyadic scores, ids / order / scores bit-identical, short lists padded."""
+    n_users, Nn, k = 70, 3000, 10
+    Hb, Eb, b = _qhead_inputs(n_users, Nn, d, True, 77)
+    Q = O.qvalues(Hb, Eb, b)
+    rng = np.random.default_rng(3)
+    rows, seen_off = [], np.zeros(n_users + 1, dtype=np.int64)
+    for u in range(n_users):
+        keep = 3 if u % 7 == 0 else int(rng.integers(k, 400))           # admissible items left for this user
+        order = np.argsort(-Q[u], kind="stable")
+        row = np.sort(order[: Nn - keep]).astype(np.int32)                  # the best Nn - keep items are seen
+        rows.append(row)
+        seen_off[u + 1] = seen_off[u] + len(row)
+        Q[u, row] = -np.inf
+    seen_items = np.concatenate(rows + [np.zeros(1, np.int32)])
+    idx_c, val_ref = O.topk_rows(Q, k)
+    idx_ref = np.where(np.isfinite(val_ref), idx_c, -1)
+    nb = int(lib.cqlrec_topk_ws_bytes(n_users, Nn, d, k))
+    ws = ws_bytes_tensor(nb)
+    out_idx = torch.empty((n_users, k), dtype=torch.int32, device=DEV)
+    out_val = torch.empty((n_users, k), dtype=torch.float32, device=DEV)
+    out_cnt = torch.empty(n_users, dtype=torch.int32, device=DEV)
+    N.check(lib.cqlrec_score_topk(ptr(bf16_dev(Hb)), n_users, ptr(bf16_dev(Eb)), ptr(dev(b)), Nn, d, None,
+                                  ptr(dev(seen_off)), ptr(dev(seen_items)), None, k, ptr(ws), nb, ptr(out_idx),
+                                  ptr(out_val), ptr(out_cnt), stream()))
+    sync()
+    valid = np.isfinite(val_ref)
+    assert np.array_equal(out_cnt.cpu().numpy(), valid.sum(1))
+    assert np.array_equal(out_idx.cpu().numpy(), idx_ref)
+    assert np.array_equal(np.where(valid, out_val.cpu().numpy(), 0), np.where(valid, val_ref, 0))
+
+
 def test_topk_candidate_subset_and_short_lists(lib):
     Nn = 3000
     cand = np.sort(np.random.default_rng(1).choice(Nn, 37, replace=False)).astype(np.int32)
@@ -482,9 +517,11 @@ def test_topk_candidate_subset_and_short_lists(lib):
     assert np.all(idx[:, kk:] == -1) and np.all(np.isneginf(val[:, kk:]))
 
 
-def test_topk_all_equal_scores(lib):
-    """cold start: every score equal -> items 0..k-1 in order (tie rule)."""
-    n_users, Nn, d, k = 9, 5000, 64, 12
+@pytest.mark.parametrize("d", [64, 128])
+def test_topk_all_equal_scores(lib, d):
+    """cold start: every score equal -> items 0..k-1 in order (tie rule).  d = 128 runs the on-chip selection, whose
+    bound must be strict against a lane's own list (every item ties with it) and non-strict against its partner's."""
+    n_users, Nn, k = 9, 5000, 12
     Hb = np.zeros((n_users, d), np.float32)
     Eb = np.zeros((Nn, d), np.float32)
     b = np.zeros(Nn, np.float32)
