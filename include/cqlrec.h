@@ -14,8 +14,8 @@
  *   - bf16 tensors are uint16_t bit patterns; matrices are row-major; W1/W2 are stored [out][in];
  *   - return value: CQLREC_OK, or a negative code with the message available from cqlrec_last_error();
  *   - the kernel-level entry points are re-entrant; the step driver (cqlrec_train_step*) keeps one set of internal
- *     side streams and events per process: drive one training context per process from one host thread (one process
- *     per GPU is the deployment model);
+ *     side streams and events per DEVICE (indexed by the calling thread's current device): drive one training context
+ *     per device from one host thread at a time (one process per GPU is the deployment model);
  *   - the training step contains no float atomics: the same calls on the same inputs give the same bits.
  */
 #ifndef CQLREC_H

@@ -36,6 +36,15 @@ void cql_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// index of the calling thread's current device into small per-device state tables (internal streams, "opt-in done"
+// flags): a process that drives several devices gets one set per device instead of silently sharing the first one's
+#define CQL_MAX_DEVICES 16
+static inline int cql_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev % CQL_MAX_DEVICES;
+}
+
 // ---- measurement hooks (see cqlrec_prof_enable) -------------------------------------------------------------
 void cql_prof_begin(int phase, hipStream_t s);
 void cql_prof_end(hipStream_t s);

@@ -573,7 +573,8 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int
 template <int D, int SPW, int MODE, int NBUF, int MINW>
 static void qs_launch_n(const QArgs& a, int64_t rblks, hipStream_t s) {
   constexpr int smem = NBUF * QCfg<D>::BUF_BYTES + (MODE == QM_TOPK ? 4 * SPW * QS_TOPK_BUF * 64 * 8 : 0);
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+  static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+  bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)qstream_kernel<D, SPW, MODE, NBUF, MINW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -371,7 +371,8 @@ int64_t cql_qde_ws_bytes(int64_t batch, int64_t n_items, int32_t d) {
 template <int D, int NBUF, int WAVES>
 static void qde_launch_n(const QDeArgs& a, int grid, hipStream_t s) {
   constexpr int smem = NBUF * DeCfg<D, WAVES>::BUF_BYTES;
-  static bool attr_set = false;
+  static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+  bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)qde_kernel<D, NBUF, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;

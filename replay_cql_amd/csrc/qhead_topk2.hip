@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256) void topk2_seen_bits_kernel(const int64_t* __r
 // host side
 // =============================================================================================================
 static int tk2_cus() {
-  static int cus = 0;
+  static int cus_dev[CQL_MAX_DEVICES] = {};
+  int& cus = cus_dev[cql_device_slot()];
   if (!cus) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -538,7 +539,8 @@ int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, cons
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s) {
   if (!cql_topk2_supported(d, a.k, a.n_cand)) return CQLREC_ERR_INVALID;
   constexpr int smem = Tk2Cfg<128>::SMEM;
-  static bool attr_set = false;
+  static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+  bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)qtopk2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;

@@ -171,9 +171,10 @@ bool concurrency_on() {
   return g_concurrency != 0;
 }
 SideStream& side_stream() {
-  static SideStream ss;
+  static SideStream per_device[CQL_MAX_DEVICES];     // streams and events belong to the device they were created on
   static SideStream off;   // never ok: serial mode
   if (!concurrency_on()) return off;
+  SideStream& ss = per_device[cql_device_slot()];
   if (!ss.tried) {
     ss.tried = true;
     // Plain streams, all of one priority class: mixing priority classes (tried: item-side backward low, branch stream
