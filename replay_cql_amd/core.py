@@ -528,34 +528,24 @@ class CQLCore:
                 hi = min(n, lo + chunk)
                 call(ws, lo, hi, hb.data_ptr() + 2 * h.d * lo, N.TOPK_ALL, s)
         else:
-            # Software pipeline over the chunks: what a chunk needs before it can be scored -- its seen bitmap (depends
-            # on the lists only) and its state vectors (window gather + encoder) -- is HBM-bound work and runs on a
-            # side stream under the MFMA-bound scoring kernel of the chunk before; two workspaces alternate.
+            # Per chunk: the seen bitmap (depends on the lists only) is built on a side stream while the chunk's state
+            # vectors (window gather + encoder) are produced on this one; the scoring kernel follows.  (Producing chunk
+            # i+1's bitmap and states UNDER the scoring of chunk i -- CQLREC_TOPK_SEEN_BESIDE, two workspaces -- was
+            # measured: the HBM-bound preparation slows the scoring kernel it runs beside by what it would cost alone,
+            # 34.5-37.8 ms per 1 M users against 33-34 ms this way, and the spread between boxes grows.)
             if self._topk_side is None:
                 self._topk_side = torch.cuda.Stream(device=self.device)
             side = self._topk_side
-            wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) for _ in range(min(2, n_chunks))]
-            scored = [torch.cuda.Event() for _ in range(n_chunks)]
-            side.wait_stream(main)
-            for i, lo in enumerate(range(0, n, chunk)):
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            for lo in range(0, n, chunk):
                 hi = min(n, lo + chunk)
-                ws_ = wss[i % 2]
-                with torch.cuda.stream(side):
-                    if i >= 2:
-                        side.wait_event(scored[i - 2])          # the workspace is free again
-                    call(ws_, lo, hi, None, N.TOPK_SEEN if i == 0 else N.TOPK_SEEN_BESIDE, side.cuda_stream)
-                    if i > 0:
-                        hb_c = hb_fn(lo, hi)
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-                if i == 0:          # nothing is being scored yet: the first chunk is encoded beside its bitmap
-                    hb_c = hb_fn(lo, hi)
-                main.wait_event(ready)
-                call(ws_, lo, hi, hb_c.data_ptr(), N.TOPK_SCORE, s)
-                scored[i].record(main)
+                side.wait_stream(main)          # the previous chunk's scoring reads the same workspace
+                call(ws, lo, hi, None, N.TOPK_SEEN, side.cuda_stream)
+                hb_c = hb_fn(lo, hi)
+                main.wait_stream(side)
+                call(ws, lo, hi, hb_c.data_ptr(), N.TOPK_SCORE, s)
                 hb_c.record_stream(main)
-            for w_ in wss:
-                w_.record_stream(side)
+            ws.record_stream(side)
         del keep
         return out_idx, out_val, out_cnt
 
@@ -565,8 +555,8 @@ class CQLCore:
                     cand_items: Optional[torch.Tensor] = None,
                     seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
                     chunk: int = 65536) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """encode(offsets, items, users) + score_topk in one pipelined pass (the predict path, S7): the seen bitmap and
-        the state vectors of chunk i+1 are produced on a side stream while chunk i is scored."""
+        """encode(offsets, items, users) + score_topk in one pass (the predict path, S7): per chunk of users the seen bitmap
+        is built on a side stream while the window gather and the encoder run."""
         if seen is not None and seen_rows is None:
             seen_rows = users.to(device=self.device, dtype=torch.int32)
         if k > self.MAX_FUSED_K:

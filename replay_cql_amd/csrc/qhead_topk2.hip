@@ -87,6 +87,12 @@ __device__ __forceinline__ float tk2_max4(float a, float b, float c, float d) {
   return q;
 }
 
+__device__ __forceinline__ float tk2_max3(float a, float b, float c) {
+  float q;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(q) : "v"(a), "v"(b), "v"(c));
+  return q;
+}
+
 template <int D>
 __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
   using T = Tk2Cfg<D>;
@@ -235,9 +241,12 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
 
   // slow path of the epilogue of one (tile, group): trow0 = global row of the tile's row 0, w = seen bits of the tile's
   // 32 rows for this lane's user.  One merge site in front of the scan (see TK2_Q); the scan itself is straight-line.
-  auto slow = [&](const f32x16& acc, const float (&qm)[4], auto G_, int64_t trow0, uint32_t w) __attribute__((always_inline)) {
+  auto slow = [&](const f32x16& acc, auto G_, int64_t trow0, uint32_t w) __attribute__((always_inline)) {
     constexpr int g = decltype(G_)::value;
     if (__builtin_amdgcn_ballot_w64(cnt[g] > TK2_Q - 16) != 0) merge(G_);
+    float qm[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qm[q] = tk2_max4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     const uint32_t wh = w >> (4 * h);
     const int lim = (int)((s_end - trow0 < 64) ? (s_end - trow0) : 64) - 4 * h;   // element admissible iff rc < lim
     const uint32_t nrow = ~((uint32_t)trow0 + 4u * (uint32_t)h);                  // ~(row0 + rc) = nrow - rc
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
   for (int i = 0; i < 16; ++i) acc1[i] = NEG_INF_F;       // "the tile before the first": nothing beats any bound
   u32x2 wv0 = {0u, 0u}, wv1 = {0u, 0u};   // seen words of the stage: .x tile 0, .y tile 1
   uint32_t w_pend = 0u;
-  float qm[4], tmx = 0.f;
+  float qm[4], tmx = 0.f;      // scratch of the fast path (qm: partial maxima)
 
   // LDS reads of the tile FOLLOWING tile IT of the current buffer: idx 0..7 rows, 8..11 bias
   auto next_read = [&](auto IT, int idx) __attribute__((always_inline)) {
@@ -300,17 +309,22 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
     if (gp == 6) asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
     return;
 #endif
+    // tile maximum of the lane's 16 scores as a v_max3 tree: 8 instructions (the quad maxima the slow path scans by are
+    // formed there, not here)
     if (gp == 3) {
-      qm[0] = tk2_max4(acc[0], acc[1], acc[2], acc[3]);
-      qm[1] = tk2_max4(acc[4], acc[5], acc[6], acc[7]);
+      qm[0] = tk2_max3(acc[0], acc[1], acc[2]);
+      qm[1] = tk2_max3(acc[3], acc[4], acc[5]);
+      qm[2] = tk2_max3(acc[6], acc[7], acc[8]);
     } else if (gp == 4) {
-      qm[2] = tk2_max4(acc[8], acc[9], acc[10], acc[11]);
-      qm[3] = tk2_max4(acc[12], acc[13], acc[14], acc[15]);
+      qm[3] = tk2_max3(acc[9], acc[10], acc[11]);
+      tmx = tk2_max3(acc[12], acc[13], acc[14]);
     } else if (gp == 5) {
-      tmx = tk2_max4(qm[0], qm[1], qm[2], qm[3]);
+      qm[0] = tk2_max3(qm[0], qm[1], qm[2]);
+      tmx = tk2_max3(qm[3], tmx, acc[15]);
+      asm("v_max_f32 %0, %1, %2" : "=v"(tmx) : "v"(qm[0]), "v"(tmx));
     } else if (gp == 6) {
 #ifndef TK2_ABL_NOBRANCH
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmx >= thr[g]) != 0, 0)) slow(acc, qm, G_, trow0, w);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmx >= thr[g]) != 0, 0)) slow(acc, G_, trow0, w);
 #else
       asm volatile("" :: "v"(tmx));
 #endif
