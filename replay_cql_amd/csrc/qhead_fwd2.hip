@@ -143,9 +143,11 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
                             // copying them back in front of every product
   bf16x8 tf[2][FT][2];
   bf16x8 dpa, dpb;
-  // half-chunks of the exponentials (qde2_kernel's; volatile asm: hipcc would otherwise regroup them).  Packed forms
+
   // (v_pk_fma_f32 for both exponent arguments, v_pk_add_f32 into a pair of partial sums: 5 instead of 7 instructions per
   // pair) were measured: slower (0.270 vs 0.200 ms) -- the packed fp32 instructions are not full rate here.
+#ifndef QF2_PACKED
+  typedef float csum_t;
   float ht0 = 0.f, ht1 = 0.f;
   auto half_a = [&](const f32x16& acc, int k, float b0) __attribute__((always_inline)) {
     asm volatile(
@@ -163,6 +165,32 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
         "v_cvt_pk_bf16_f32 %2, %0, %1"
         : "+v"(ht0), "+v"(ht1), "=&v"(w), "+v"(csum));
   };
+  auto csum_total = [](float c) __attribute__((always_inline)) { return c; };
+#else
+  // packed form: v_pk_fma_f32 forms both exponent arguments (accumulator elements 2k, 2k+1 are a register pair),
+  // v_pk_add_f32 adds both values to a pair of partial sums (even / odd elements)
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef f32x2 csum_t;
+  f32x2 ht = {0.f, 0.f};
+  f32x2 l2e2 = {CQL_LOG2E, CQL_LOG2E};
+  asm volatile("" : "+v"(l2e2));
+  auto half_a = [&](const f32x16& acc, int k, float b0) __attribute__((always_inline)) {
+    const f32x2 a2 = {acc[2 * k], acc[2 * k + 1]};
+    const f32x2 b2 = {b0, b0};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,1]" : "=&v"(ht) : "v"(a2), "v"(l2e2), "v"(b2));
+    float e0 = ht[0];
+    asm volatile("v_exp_f32 %0, %0" : "+v"(e0));
+    ht[0] = e0;
+  };
+  auto half_b = [&](uint32_t& w, f32x2& csum) __attribute__((always_inline)) {
+    float e1 = ht[1];
+    asm volatile("v_exp_f32 %0, %0" : "+v"(e1));
+    ht[1] = e1;
+    asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,1]" : "+v"(csum) : "v"(ht));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(ht[0]), "v"(ht[1]));
+  };
+  auto csum_total = [](f32x2 c) __attribute__((always_inline)) { return c[0] + c[1]; };
+#endif
   auto frag = [](const uint32_t (&pw)[8], int s2) __attribute__((always_inline)) {
     u32x4 v = {pw[4 * s2 + 0], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
     return __builtin_bit_cast(bf16x8, v);
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
     constexpr int P = decltype(IT)::value & 1;
     constexpr bool END = decltype(IT)::value == C::TILES - 1;
     uint32_t pw0[8], pw1[8];
-    float c0 = 0.f, c1 = 0.f;
+    csum_t c0 = {}, c1 = {};
     bf16x8 pa0 = {}, pb0 = {}, pa1 = {};
 #pragma unroll
     for (int gp = 0; gp < 32; ++gp) {
@@ -263,8 +291,8 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
       gap_read(IT, gp);
       QF2_FENCE();
     }
-    cs[0] += c0;
-    cs[1] += c1;
+    cs[0] += csum_total(c0);
+    cs[1] += csum_total(c1);
     dpa = pa1;
     dpb = frag(pw1, 1);
   };

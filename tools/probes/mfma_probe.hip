@@ -132,6 +132,33 @@ __global__ __launch_bounds__(256, 1) void probe(unsigned long long* out, float* 
         acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], __builtin_bit_cast(bf16x8, u), acc[s & 3], 0, 0, 0);
         FENCE();
       }
+    } else if constexpr (MODE == 14 || MODE == 15) {   // v_mfma_f32_16x16x32_bf16 (half the flops of a 32x32x16): chain / independent
+      typedef __attribute__((ext_vector_type(4))) float f32x4_;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        f32x4_ c4 = {acc[MODE == 14 ? 0 : s][0], acc[MODE == 14 ? 0 : s][1], acc[MODE == 14 ? 0 : s][2], acc[MODE == 14 ? 0 : s][3]};
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s], b[s], c4, 0, 0, 0);
+        acc[MODE == 14 ? 0 : s][0] = c4[0]; acc[MODE == 14 ? 0 : s][1] = c4[1];
+        acc[MODE == 14 ? 0 : s][2] = c4[2]; acc[MODE == 14 ? 0 : s][3] = c4[3];
+        FENCE();
+      }
+    } else if constexpr (MODE >= 16 && MODE <= 19) {   // VALU rates without any MFMA: 8 instructions per "slot"
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if constexpr (MODE == 16) asm volatile("v_exp_f32 %0, %0" : "+v"(v[s]));
+        else if constexpr (MODE == 17) asm volatile("v_fmamk_f32 %0, %0, 0x3fb8aa3b, %1" : "+v"(v[s]) : "v"(v[15]));
+        else if constexpr (MODE == 18) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2_;
+          f32x2_ x = {v[2 * (s & 3)], v[2 * (s & 3) + 1]}, y2 = {v[8], v[9]}, z2 = {v[10], v[11]};
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(y2), "v"(z2));
+          v[2 * (s & 3)] = x[0]; v[2 * (s & 3) + 1] = x[1];
+        } else {
+          unsigned w;
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(v[s]), "v"(v[s + 8]));
+          v[s] = __uint_as_float(w);
+        }
+        FENCE();
+      }
     } else if constexpr (MODE == 7) {   // VALU reads the accumulator of a chain that ended 3 MFMAs ago (acc -> exp -> pack)
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -188,6 +215,12 @@ int main() {
     run<11>("chain + 4 ds_read_b128 per MFMA (not consumed)", w, d_out, d_sink, d_src);
     run<12>("chain + chunk + 1 ds_read_b128 per MFMA", w, d_out, d_sink, d_src);
     run<13>("chain + half-chunks (3 / 4 VALU) behind alternate MFMAs", w, d_out, d_sink, d_src);
+    run<14>("16x16x32 bf16, dependent chain (half the flops per MFMA)", w, d_out, d_sink, d_src);
+    run<15>("16x16x32 bf16, 8 independent accumulators", w, d_out, d_sink, d_src);
+    run<16>("no MFMA: v_exp_f32 (cycles per instruction)", w, d_out, d_sink, d_src);
+    run<17>("no MFMA: v_fmamk_f32", w, d_out, d_sink, d_src);
+    run<18>("no MFMA: v_pk_fma_f32 (two fp32 FMAs)", w, d_out, d_sink, d_src);
+    run<19>("no MFMA: v_cvt_pk_bf16_f32", w, d_out, d_sink, d_src);
   }
   return 0;
 }
