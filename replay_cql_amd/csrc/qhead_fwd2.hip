@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
   bf16x8 tf[2][FT][2];
   bf16x8 dpa, dpb;
 
-  // (v_pk_fma_f32 for both exponent arguments, v_pk_add_f32 into a pair of partial sums: 5 instead of 7 instructions per
-  // pair) were measured: slower (0.270 vs 0.200 ms) -- the packed fp32 instructions are not full rate here.
+  // half-chunks of the exponentials (qde2_kernel's; volatile asm: hipcc would otherwise regroup them).  -DQF2_PACKED
+  // selects packed forms (v_pk_fma_f32 for both exponent arguments, v_pk_add_f32 into a pair of partial sums: 5 instead
+  // of 7 instructions per pair) -- correct, but slower beside MFMAs (0.266 vs 0.198 ms): kept for A/B only.
 #ifndef QF2_PACKED
   typedef float csum_t;
   float ht0 = 0.f, ht1 = 0.f;
