@@ -138,9 +138,8 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
 
 #define QF2_FENCE() __builtin_amdgcn_sched_barrier(0)
   bf16x8 af[KS];            // row fragments and bias of ONE tile: those of tile t+1 replace tile t's one by one, each right
-  f32x16 sv;                // behind its last use (B(t) reads row s in gap 5+s and the bias in gap 5) -- 48 registers less
-  f32x16 acc0, acc1;        // than two sets, which is what keeps hipcc from parking owner fragments in AccVGPRs and
-                            // copying them back in front of every product
+  f32x16 sv;                // behind its last use (B(t) reads row s in gap 5+s and the bias in gap 5).  hipcc renames them
+  f32x16 acc0, acc1;        // into two register sets anyway where it has room; the source asks for one.
   bf16x8 tf[2][FT][2];
   bf16x8 dpa, dpb;
 
