@@ -640,7 +640,8 @@ static int qs_launch_switch(int mode, const QArgs& a, int d, int64_t rblks, hipS
 // finalize / reduce kernels
 // =============================================================================================================
 __global__ void qhead_finalize_lse_kernel(const float* __restrict__ pm, const float* __restrict__ pl, int nsplit,
-                                          int64_t rows, float* __restrict__ lse, float* __restrict__ nlse2) {
+                                          int64_t rows, float* __restrict__ lse, float* __restrict__ nlse2,
+                                          float* __restrict__ nlse_nat = nullptr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   float M = NEG_INF;
@@ -652,7 +653,11 @@ __global__ void qhead_finalize_lse_kernel(const float* __restrict__ pm, const fl
   for (int s = 0; s < nsplit; ++s) L += pl[(int64_t)s * rows + r] * fast_exp2((pm[(int64_t)s * rows + r] - ms) * CQL_LOG2E);
   const float v = ms + logf(L);
   lse[r] = v;
-  if (nlse2) nlse2[r] = -v * CQL_LOG2E;
+  if (nlse2) {
+    const float n2 = -v * CQL_LOG2E;
+    nlse2[r] = n2;
+    if (nlse_nat) nlse_nat[r] = n2 * CQL_LN2;      // exactly what qde_nlse_natural_kernel would form from nlse2
+  }
 }
 
 // ARGMAX finalize: pick, per row, the slice partial with the largest maximum (ties: the earliest tile), then resolve
@@ -949,7 +954,7 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
                                int64_t batch, const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d,
                                float scale, void* ws, int64_t ws_bytes, float* g_E_out, float* g_b_out,
                                cqlrec_stream stream, bool sparse_first, bool do_sparse = true, int64_t item_lo = 0,
-                               int64_t item_hi = -1, CqlAdamFix* defer = nullptr) {
+                               int64_t item_hi = -1, CqlAdamFix* defer = nullptr, const float* nlse_nat = nullptr) {
   if (defer) defer->valid = 0;
   if (item_hi < 0) item_hi = n_items;
   CQL_REQUIRE(item_lo >= 0 && item_lo < item_hi && item_hi <= n_items, "qhead_bwd_items: bad item range");
@@ -1013,7 +1018,7 @@ static int qhead_bwd_items_impl(const uint16_t* H_b, const float* nlse2, const f
   if (use_qde) {
     const int rc = cql_qde_launch(H_b, nlse2, batch, E_out_b + item_lo * d, b_out + item_lo, item_hi - item_lo, d, scale,
                                   ws, ws_bytes, g_E_out + item_lo * d, g_b_out + item_lo, sparse_first ? 1 : 0, s,
-                                  (item_lo == 0 && item_hi == n_items) ? defer : nullptr);
+                                  (item_lo == 0 && item_hi == n_items) ? defer : nullptr, nlse_nat);
     if (rc != CQLREC_OK) return rc;
   } else {
     const int64_t rblks_all = (n_items + 127) / 128;
@@ -1052,7 +1057,8 @@ static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
 }
 
 int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
-                         int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t s) {
+                         int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t s,
+                         float* out_nlse_nat) {
   CQL_REQUIRE(H_b && E_out_b && b_out && ws && out_lse, "qhead_fwd_lse_dh: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_fwd_lse_dh: d=%d unsupported", d);
   CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd_lse_dh: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
@@ -1102,7 +1108,7 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
   }
   CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
   hipLaunchKernelGGL(qhead_finalize_lse_kernel, dim3(cql_ceil_div(rows, 256)), dim3(256), 0, s, a.part_a, a.part_b,
-                     a.nsplit, rows, out_lse, out_nlse2);
+                     a.nsplit, rows, out_lse, out_nlse2, out_nlse_nat);
   CQL_LAUNCH_CHECK("qhead_fwd_lse_dh");
   return CQLREC_OK;
 }
@@ -1129,7 +1135,8 @@ extern "C" int64_t cqlrec_qhead_fused_ws_bytes(int64_t rows, int64_t n_items, in
 extern "C" int cqlrec_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
                                        int64_t n_items, int32_t d, void* ws, int64_t ws_bytes, float* out_lse,
                                        float* out_nlse2, cqlrec_stream stream) {
-  return cql_qhead_fwd_lse_dh(H_b, rows, E_out_b, b_out, n_items, d, ws, ws_bytes, out_lse, out_nlse2, (hipStream_t)stream);
+  return cql_qhead_fwd_lse_dh(H_b, rows, E_out_b, b_out, n_items, d, ws, ws_bytes, out_lse, out_nlse2, (hipStream_t)stream,
+                              nullptr);
 }
 extern "C" int cqlrec_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse,
                                       const float* coef, const int32_t* act, const uint16_t* E_out_b, float scale,
@@ -1140,9 +1147,9 @@ extern "C" int cqlrec_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_it
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,
-                            int64_t item_lo, int64_t item_hi, CqlAdamFix* defer) {
+                            int64_t item_lo, int64_t item_hi, CqlAdamFix* defer, const float* nlse_nat) {
   return qhead_bwd_items_impl(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
-                              g_b_out, (cqlrec_stream)stream, true, do_sparse != 0, item_lo, item_hi, defer);
+                              g_b_out, (cqlrec_stream)stream, true, do_sparse != 0, item_lo, item_hi, defer, nlse_nat);
 }
 
 extern "C" int cqlrec_qhead_bwd(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act,

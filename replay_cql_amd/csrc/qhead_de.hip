@@ -398,7 +398,7 @@ static void qde_fixup_d(const QDeArgs& a, int grid, int waves, hipStream_t s) {
 // g_E_out / g_b_out rows [0, n_items) of this call: out (+)= scale * dE (accumulate: on top of what is there)
 int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const uint16_t* E_b, const float* bias,
                    int64_t n_items, int32_t d, float scale, void* ws, int64_t ws_bytes, float* out, float* out_cs,
-                   int accumulate, hipStream_t s, CqlAdamFix* defer) {
+                   int accumulate, hipStream_t s, CqlAdamFix* defer, const float* nlse_nat) {
   if (defer) defer->valid = 0;
   CQL_REQUIRE(ws_bytes >= cql_qde_ws_bytes(batch, n_items, d), "qde: workspace too small");
   CQL_REQUIRE(batch * 2 * d < (1ll << 31), "qde: batch=%lld too large for one buffer descriptor", (long long)batch);
@@ -426,12 +426,16 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
                                                          de_align256(batch * 4));
   a.stamps = want_stamps ? stamps_dev : nullptr;
   if (form2) {
-    float* nat = (float*)((char*)a.slab_cs + de_align256((int64_t)grid * items * 4));
-    {
-      CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
-      hipLaunchKernelGGL(qde_nlse_natural_kernel, dim3(cql_ceil_div(batch, 256)), dim3(256), 0, s, nlse2, batch, nat);
+    if (nlse_nat) {        // the caller's forward already wrote -lse in natural units
+      a.nlse2 = nlse_nat;
+    } else {
+      float* nat = (float*)((char*)a.slab_cs + de_align256((int64_t)grid * items * 4));
+      {
+        CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+        hipLaunchKernelGGL(qde_nlse_natural_kernel, dim3(cql_ceil_div(batch, 256)), dim3(256), 0, s, nlse2, batch, nat);
+      }
+      a.nlse2 = nat;
     }
-    a.nlse2 = nat;
     CqlProfScope prof(CQLREC_PH_QHEAD_BWD_DE, s);
     const int rc = cql_qde2_run(a, d, grid, s);
     if (rc != CQLREC_OK) return rc;

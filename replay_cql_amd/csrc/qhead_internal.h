@@ -72,21 +72,22 @@ int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
 // coefficients are known:  dH[b] = scale * sum_k slab_k[b] * exp(m_k[b] - lse[b]) + coef[b] * E_out_b[act[b]].
 // ws: cqlrec_qhead_bwd_ws_bytes(rows, n_items, d) + cqlrec_qhead_ws_bytes(rows, n_items, d) bytes.
 int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
-                         int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t stream);
+                         int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t stream,
+                         float* out_nlse_nat = nullptr);      // out_nlse_nat: -lse in natural units (what qde2 wants)
 int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse, const float* coef,
                         const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t stream);
 // do_sparse: issue the scatter in this call; [item_lo, item_hi): item rows the streaming kernel handles in this call.
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,
-                            int64_t item_lo, int64_t item_hi, CqlAdamFix* defer = nullptr);
+                            int64_t item_lo, int64_t item_hi, CqlAdamFix* defer = nullptr, const float* nlse_nat = nullptr);
 
 
 // qhead_de.hip: the item-side backward as a persistent, statically balanced kernel (rows [0, n_items) of E_b / bias / out)
 int64_t cql_qde_ws_bytes(int64_t batch, int64_t n_items, int32_t d);
 int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const uint16_t* E_b, const float* bias,
                    int64_t n_items, int32_t d, float scale, void* ws, int64_t ws_bytes, float* out, float* out_cs,
-                   int accumulate, hipStream_t s, CqlAdamFix* defer = nullptr);
+                   int accumulate, hipStream_t s, CqlAdamFix* defer = nullptr, const float* nlse_nat = nullptr);
 
 // qhead_topk2.hip: the top-K pass as a one-wave-per-SIMD kernel with on-chip selection (d = 128, k <= 16, whole catalogue)
 struct QTk2Args {

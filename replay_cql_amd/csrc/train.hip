@@ -50,7 +50,7 @@ struct Carve {
 
 struct StepWs {
   int32_t *users, *tpos, *act, *a_star;
-  float *rew, *done, *q_a, *lse, *nlse2, *q_targ, *y, *coef, *maxv, *loss;
+  float *rew, *done, *q_a, *lse, *nlse2, *nlse_nat, *q_targ, *y, *coef, *maxv, *loss;
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
   void *ws_q, *ws_q2, *ws_qb, *ws_qb2, *ws_enc, *ws_gb, *ws_oh;
@@ -70,6 +70,7 @@ void carve_small(Carve& c, StepWs& w, int32_t B, int32_t d) {
   w.q_a = c.take<float>(B);
   w.lse = c.take<float>(B);
   w.nlse2 = c.take<float>(B);
+  w.nlse_nat = c.take<float>(B);
   w.q_targ = c.take<float>(B);
   w.y = c.take<float>(B);
   w.coef = c.take<float>(B);
@@ -319,7 +320,7 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   if (eout_ready) CQL_HIP_TRY(hipStreamWaitEvent(s, eout_ready, 0), "train_step_forward");
   if (corun) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.bpro, 0), "train_step_forward");
   // logsumexp AND the softmax-weighted sum of item rows (the soft part of dH) in ONE pass over the catalogue
-  CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s));
+  CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s, w.nlse_nat));
   if (g_mark_phase == 2) mark(MK_LSE, s);
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
@@ -359,7 +360,7 @@ int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
                              (hipStream_t)stream));
   return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, alpha_scale(c),
                                  w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
-                                 (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1, defer);
+                                 (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1, defer, w.nlse_nat);
 }
 
 // records `dh` behind dh_finish, the last reader of the E_out shadow on this stream: the item-side Adam waits for it
