@@ -528,24 +528,34 @@ class CQLCore:
                 hi = min(n, lo + chunk)
                 call(ws, lo, hi, hb.data_ptr() + 2 * h.d * lo, N.TOPK_ALL, s)
         else:
-            # Per chunk: the seen bitmap (depends on the lists only) is built on a side stream while the chunk's state
-            # vectors (window gather + encoder) are produced on this one; the scoring kernel follows.  (Producing chunk
-            # i+1's bitmap and states UNDER the scoring of chunk i -- CQLREC_TOPK_SEEN_BESIDE, two workspaces -- was
-            # measured: the HBM-bound preparation slows the scoring kernel it runs beside by what it would cost alone,
-            # 34.5-37.8 ms per 1 M users against 33-34 ms this way, and the spread between boxes grows.)
+            # The state vectors of chunk i+1 (window gather + encoder: small kernels, no LDS to speak of) are produced on a
+            # side stream while chunk i is scored; the seen bitmap (820 MB of writes per 65 536 users x 100 000 items, and
+            # a 48 KiB LDS tile per block that cannot be resident beside the scoring kernel anyway) is built on this
+            # stream, in front of the scoring kernel that reads it.  (Also measured: bitmap AND states under the scoring
+            # of the chunk before -- CQLREC_TOPK_SEEN_BESIDE, two workspaces: the HBM-bound bitmap slows the scoring
+            # kernel by what it would cost alone; bitmap beside the encoder only: 2.19 ms per chunk, this order 2.0.)
             if self._topk_side is None:
                 self._topk_side = torch.cuda.Stream(device=self.device)
             side = self._topk_side
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-            for lo in range(0, n, chunk):
-                hi = min(n, lo + chunk)
-                side.wait_stream(main)          # the previous chunk's scoring reads the same workspace
-                call(ws, lo, hi, None, N.TOPK_SEEN, side.cuda_stream)
-                hb_c = hb_fn(lo, hi)
-                main.wait_stream(side)
+            bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
+
+            def encode_on_side(lo, hi):
+                with torch.cuda.stream(side):
+                    hb_c = hb_fn(lo, hi)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return hb_c, ev
+            side.wait_stream(main)
+            nxt = encode_on_side(*bounds[0])
+            for i, (lo, hi) in enumerate(bounds):
+                hb_c, ready = nxt
+                if i + 1 < len(bounds):
+                    nxt = encode_on_side(*bounds[i + 1])
+                call(ws, lo, hi, None, N.TOPK_SEEN, s)
+                main.wait_event(ready)
                 call(ws, lo, hi, hb_c.data_ptr(), N.TOPK_SCORE, s)
                 hb_c.record_stream(main)
-            ws.record_stream(side)
         del keep
         return out_idx, out_val, out_cnt
 
@@ -555,8 +565,8 @@ class CQLCore:
                     cand_items: Optional[torch.Tensor] = None,
                     seen: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seen_rows: Optional[torch.Tensor] = None,
                     chunk: int = 65536) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """encode(offsets, items, users) + score_topk in one pass (the predict path, S7): per chunk of users the seen bitmap
-        is built on a side stream while the window gather and the encoder run."""
+        """encode(offsets, items, users) + score_topk in one pass (the predict path, S7): the state vectors of chunk i+1
+        are produced on a side stream while chunk i is scored."""
         if seen is not None and seen_rows is None:
             seen_rows = users.to(device=self.device, dtype=torch.int32)
         if k > self.MAX_FUSED_K:
