@@ -628,6 +628,60 @@ __global__ __launch_bounds__(256) void topk_seen_bits_kernel(const int64_t* __re
   }
 }
 
+// The same merge for at most four lists per user (item slices <= 2, the usual case: one block per CU needs no slicing
+// from 65 536 users on), one WAVE per user: lane l holds key l & 15 of list l >> 4; the rank of a key in the union is
+// its position in its own list plus, per other list, the number of keys there that beat it -- a 5-step binary search
+// through wave shuffles over that list's 16 lanes (lists are sorted, keys distinct).  Keys of rank < k go straight to
+// their output slot: no loop over k, no per-thread scratch arrays, coalesced loads (the per-thread form above took
+// 70-100 us per 65 536 users, this one ~10).
+__global__ __launch_bounds__(256) void topk_merge_wave_kernel(const unsigned long long* __restrict__ keys, int nsplit,
+                                                              int64_t n_users, const int32_t* __restrict__ item_ids, int k,
+                                                              int32_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                              int32_t* __restrict__ out_cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_users) return;
+  const int nl = 2 * nsplit, lst = lane >> 4, j = lane & 15;
+  unsigned long long key = 0ull;
+  if (lst < nl) key = keys[(((int64_t)(lst >> 1) * n_users + u) * 2 + (lst & 1)) * QS_TOPK_K + j];
+  int rank = j;
+  for (int m = 0; m < nl; ++m) {
+    // number of keys of list m greater than `key`: binary search over lanes 16 m .. 16 m + 15 (descending order)
+    int pos = 0;
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1) {
+      const unsigned long long probe = __shfl(key, 16 * m + pos + step - 1);
+      if (probe > key) pos += step;
+    }
+    const unsigned long long last = __shfl(key, 16 * m + pos);      // pos <= 15
+    if (last > key) pos += 1;
+    if (m != lst) rank += pos;
+  }
+  const bool take = (lst < nl) && key != 0ull && rank < k;
+  const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(take));
+  if (take) {
+    const uint32_t c = ~(uint32_t)(key & 0xFFFFFFFFull);
+    out_idx[u * k + rank] = item_ids ? item_ids[c] : (int32_t)c;
+    out_val[u * k + rank] = f32_from_order_key((uint32_t)(key >> 32));
+  }
+  if (lane >= cnt && lane < k) {
+    out_idx[u * k + lane] = -1;
+    out_val[u * k + lane] = NEG_INF_F;
+  }
+  if (lane == 0) out_cnt[u] = cnt;
+}
+
+// launches the merge of the per-(slice, user, lane half) lists
+static void tk_launch_merge(const unsigned long long* keys, int nsplit, int64_t n_users, const int32_t* item_ids, int k,
+                            int32_t* out_idx, float* out_val, int32_t* out_cnt, hipStream_t s) {
+  if (2 * nsplit <= 4)
+    hipLaunchKernelGGL(topk_merge_wave_kernel, dim3(cql_ceil_div(n_users, 4)), dim3(256), 0, s, keys, nsplit, n_users,
+                       item_ids, k, out_idx, out_val, out_cnt);
+  else
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(cql_ceil_div(n_users, 256)), dim3(256), 0, s, keys, nsplit, n_users, item_ids,
+                       k, out_idx, out_val, out_cnt);
+}
+
 static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 static inline int64_t tk_bits_words(int64_t n_cand) { return ((n_cand + 31) / 32 + 3) / 4 * 4; }
 #define TK_FUSED_MAX_SPLIT 32
@@ -742,8 +796,7 @@ extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, con
       if (rc != CQLREC_OK) return rc;
     }
     CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(cql_ceil_div(n_users, 256)), dim3(256), 0, s,
-                       (const unsigned long long*)ws, a2.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt);
+    tk_launch_merge((const unsigned long long*)ws, a2.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt, s);
     CQL_LAUNCH_CHECK("score_topk (topk2)");
     return CQLREC_OK;
   }
@@ -777,8 +830,7 @@ extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, con
     a.seen_w = W;
     qs_launch(QM_TOPK, a, d, sp.rblks, s);
     CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(cql_ceil_div(n_users, 256)), dim3(256), 0, s,
-                       (const unsigned long long*)ws, sp.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt);
+    tk_launch_merge((const unsigned long long*)ws, sp.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt, s);
     CQL_LAUNCH_CHECK("score_topk (fused)");
     return CQLREC_OK;
   }
