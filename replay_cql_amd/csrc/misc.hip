@@ -2,6 +2,7 @@
 // gfx950 only.  Algorithmic bytes per unit are listed in DESIGN.md.
 #include <stdlib.h>
 #include "common.h"
+#include "adam_math.h"
 
 // =============================================================================================================
 // error plumbing
@@ -598,32 +599,6 @@ extern "C" int cqlrec_td_loss(const float* q_a, const float* lse, const float* q
 // fused Adam + Polyak + bf16 shadows.  Pure HBM streaming: 20 B read + 24 B written per parameter.
 // Compiled with -ffp-contract=off so the expression order below is the normative one (oracle.adam_ema_step).
 // =============================================================================================================
-// NT: the fp32 streams (read once, written once per step) bypass the caches with non-temporal accesses, so that this
-// kernel does not evict the bf16 E_out shadow -- which the Q-head kernels keep re-reading from L2 / Infinity Cache --
-// when it runs next to them; the bf16 shadows it writes stay cacheable (they are what the next kernels read).
-template <bool NT>
-__device__ __forceinline__ float4 ld4(const float4* p) {
-  if constexpr (NT) {
-    const float* f = reinterpret_cast<const float*>(p);
-    return make_float4(__builtin_nontemporal_load(f), __builtin_nontemporal_load(f + 1), __builtin_nontemporal_load(f + 2),
-                       __builtin_nontemporal_load(f + 3));
-  } else {
-    return *p;
-  }
-}
-template <bool NT>
-__device__ __forceinline__ void st4(float4* p, float a, float b, float c, float d) {
-  if constexpr (NT) {
-    float* f = reinterpret_cast<float*>(p);
-    __builtin_nontemporal_store(a, f);
-    __builtin_nontemporal_store(b, f + 1);
-    __builtin_nontemporal_store(c, f + 2);
-    __builtin_nontemporal_store(d, f + 3);
-  } else {
-    *p = make_float4(a, b, c, d);
-  }
-}
-
 template <bool NT>
 __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ theta, float4* __restrict__ grads,
                                                        float4* __restrict__ m, float4* __restrict__ v,
@@ -640,11 +615,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float4* __restrict__ thet
           tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      mm[k] = beta1 * mm[k] + omb1 * g[k];
-      vv[k] = beta2 * vv[k] + (omb2 * g[k]) * g[k];
-      const float denom = sqrtf(vv[k]) / sqrt_bc2 + eps;
-      p[k] = p[k] - step_size * (mm[k] / denom);
-      tt[k] = omt * tt[k] + tau * p[k];
+      adam_ema_elem(g[k], p[k], mm[k], vv[k], tt[k], step_size, sqrt_bc2, beta1, beta2, eps, tau, omb1, omb2, omt);
     }
     st4<NT>(theta + i, p[0], p[1], p[2], p[3]);
     st4<NT>(m + i, mm[0], mm[1], mm[2], mm[3]);
@@ -712,11 +683,7 @@ __global__ __launch_bounds__(256) void adam_ema_fix_kernel(float4* __restrict__ 
           tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      mm[k] = beta1 * mm[k] + omb1 * g[k];
-      vv[k] = beta2 * vv[k] + (omb2 * g[k]) * g[k];
-      const float denom = sqrtf(vv[k]) / sqrt_bc2 + eps;
-      p[k] = p[k] - step_size * (mm[k] / denom);
-      tt[k] = omt * tt[k] + tau * p[k];
+      adam_ema_elem(g[k], p[k], mm[k], vv[k], tt[k], step_size, sqrt_bc2, beta1, beta2, eps, tau, omb1, omb2, omt);
     }
     st4<NT>(theta + i, p[0], p[1], p[2], p[3]);
     st4<NT>(m + i, mm[0], mm[1], mm[2], mm[3]);

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64 * WAVES, (D == 256 ? 1 : 2)) void qde_kernel(QDe
 // out[group rows] += scale * slab pieces of the blocks whose range starts inside the group (in block order)
 template <int D, int QDE_ITEMS>
 __global__ __launch_bounds__(256) void qde_fixup_kernel(QDeArgs a, int nblk) {
+#pragma clang fp contract(off)      // product, then sum: the bits of the deferred fix-up (cql_adam_ema_fix, misc.hip)
   const int g = blockIdx.x;
   const int64_t W = (int64_t)a.G * a.T;
   const int64_t lo = (int64_t)g * a.T, hi = lo + a.T;

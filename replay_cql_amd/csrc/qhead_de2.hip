@@ -29,6 +29,14 @@
 #define QDE2_VALU_PER_MFMA 8   // VALU instructions the scheduler is asked to place behind each MFMA of slots 2 and 3
 #endif
 
+// out + scale * y as a product and a sum (never an fma): the terms and their order are those of the fix-up kernel and of
+// the deferred fix-up (misc.hip is compiled without contraction), so every path to the gradient gives the same bits
+__device__ __forceinline__ float qde2_axpy(float w, float scale, float u) {
+#pragma clang fp contract(off)
+  const float su = scale * u;
+  return w + su;
+}
+
 template <int D, bool MASK>
 __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
   using C = DeCfg<D, 4>;
@@ -133,15 +141,18 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float4* pd = reinterpret_cast<float4*>(dst + ft * 32 + 8 * q + 4 * h);
-              float4 o = make_float4(a.scale * y[gi][ft][4 * q + 0], a.scale * y[gi][ft][4 * q + 1],
-                                     a.scale * y[gi][ft][4 * q + 2], a.scale * y[gi][ft][4 * q + 3]);
+              float4 o;
               if (a.accumulate) {
                 const float4 old = *pd;
-                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                o = make_float4(qde2_axpy(old.x, a.scale, y[gi][ft][4 * q + 0]), qde2_axpy(old.y, a.scale, y[gi][ft][4 * q + 1]),
+                                qde2_axpy(old.z, a.scale, y[gi][ft][4 * q + 2]), qde2_axpy(old.w, a.scale, y[gi][ft][4 * q + 3]));
+              } else {
+                o = make_float4(a.scale * y[gi][ft][4 * q + 0], a.scale * y[gi][ft][4 * q + 1],
+                                a.scale * y[gi][ft][4 * q + 2], a.scale * y[gi][ft][4 * q + 3]);
               }
               *pd = o;
             }
-          if (h == 0) a.out_cs[row] = a.accumulate ? a.out_cs[row] + a.scale * csum : a.scale * csum;
+          if (h == 0) a.out_cs[row] = a.accumulate ? qde2_axpy(a.out_cs[row], a.scale, csum) : a.scale * csum;
         }
       } else {
         const int64_t srow = (int64_t)blockIdx.x * QDE2_ITEMS + wave * 64 + gi * 32 + r;

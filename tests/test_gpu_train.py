@@ -131,7 +131,8 @@ def test_pipelined_steps_match_step_by_step():
     assert np.array_equal(v["tpos"].cpu().numpy(), O.positions_to_transitions(pos, a._csr[0].cpu().numpy())[1])
 
 
-@pytest.mark.parametrize("U,Nn,d,B,L", [(300, 1000, 128, 256, 8), (200, 66000, 64, 128, 6)])
+@pytest.mark.parametrize("U,Nn,d,B,L", [(300, 1000, 128, 256, 8), (200, 66000, 64, 128, 6),
+                                          (200, 66000, 128, 128, 6), (200, 70001, 128, 192, 6)])
 def test_steps_are_bit_reproducible(U, Nn, d, B, L):
     """No float atomics anywhere in the step (sorted segmented sums for both scatters, ordered slab reductions), so the
     same steps give the same bits: run to run, and pipelined (side streams, cross-step overlap) vs strict program
