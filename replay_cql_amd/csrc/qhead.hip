@@ -1056,9 +1056,21 @@ static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
   return f;
 }
 
+// the overflow flag of the one-wave-per-SIMD form, cleared ahead of time: a caller whose catalogue pass waits for an event
+// (the item-side optimizer) clears it in front of that wait, off the critical path, and passes flag_cleared = 1
+int cql_qhead_fwd_lse_dh_prepare(void* ws, int64_t rows, int64_t n_items, int32_t d, hipStream_t s) {
+  if (!cql_qfwd2_supported(d, n_items)) return CQLREC_OK;
+  const FusedWs f = fused_ws(ws, rows, n_items, d);
+  if (hipMemsetAsync(f.flag, 0, 4, s) != hipSuccess) {
+    cql_set_error("qhead_fwd_lse_dh: hipMemsetAsync failed");
+    return CQLREC_ERR_HIP;
+  }
+  return CQLREC_OK;
+}
+
 int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                          int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t s,
-                         float* out_nlse_nat) {
+                         float* out_nlse_nat, int flag_cleared) {
   CQL_REQUIRE(H_b && E_out_b && b_out && ws && out_lse, "qhead_fwd_lse_dh: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_fwd_lse_dh: d=%d unsupported", d);
   CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd_lse_dh: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
@@ -1079,7 +1091,7 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
   if (cql_qfwd2_supported(d, n_items)) {
     // one wave per SIMD, fixed per-slice reference (qhead_fwd2.hip); the first form follows, guarded by the flag the
     // second sets when a partial sum overflowed -- its blocks return at once otherwise
-    if (hipMemsetAsync(f.flag, 0, 4, s) != hipSuccess) {
+    if (!flag_cleared && hipMemsetAsync(f.flag, 0, 4, s) != hipSuccess) {
       cql_set_error("qhead_fwd_lse_dh: hipMemsetAsync failed");
       return CQLREC_ERR_HIP;
     }

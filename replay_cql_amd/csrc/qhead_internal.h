@@ -73,7 +73,9 @@ int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
 // ws: cqlrec_qhead_bwd_ws_bytes(rows, n_items, d) + cqlrec_qhead_ws_bytes(rows, n_items, d) bytes.
 int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                          int32_t d, void* ws, int64_t ws_bytes, float* out_lse, float* out_nlse2, hipStream_t stream,
-                         float* out_nlse_nat = nullptr);      // out_nlse_nat: -lse in natural units (what qde2 wants)
+                         float* out_nlse_nat = nullptr,       // out_nlse_nat: -lse in natural units (what qde2 wants)
+                         int flag_cleared = 0);               // cql_qhead_fwd_lse_dh_prepare ran on this stream already
+int cql_qhead_fwd_lse_dh_prepare(void* ws, int64_t rows, int64_t n_items, int32_t d, hipStream_t s);
 int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse, const float* coef,
                         const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t stream);
 // do_sparse: issue the scatter in this call; [item_lo, item_hi): item rows the streaming kernel handles in this call.

@@ -317,10 +317,11 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, B, d, 1, nullptr, w.zb, stream));
   CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, B, d, 0, nullptr, w.hb, stream));
   if (g_mark_phase == 2) mark(MK_PROLOGUE, s);
+  CQL_TRY(cql_qhead_fwd_lse_dh_prepare(w.ws_qb, B, N, d, s));      // (a 4-byte memset: in front of the wait, not behind it)
   if (eout_ready) CQL_HIP_TRY(hipStreamWaitEvent(s, eout_ready, 0), "train_step_forward");
   if (corun) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.bpro, 0), "train_step_forward");
   // logsumexp AND the softmax-weighted sum of item rows (the soft part of dH) in ONE pass over the catalogue
-  CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s, w.nlse_nat));
+  CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s, w.nlse_nat, 1));
   if (g_mark_phase == 2) mark(MK_LSE, s);
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
