@@ -259,7 +259,7 @@ def test_cfg5_shard_shape_properties():
         torch.testing.assert_close(val[u], Q[u, idx[u].long()], rtol=0, atol=1e-3)
 
 
-@pytest.mark.parametrize("d,chunk", [(128, 1536), (64, 4000)])
+@pytest.mark.parametrize("d,chunk", [(128, 1536), (128, 700), (64, 4000)])
 def test_encode_topk_pipelined_equals_two_calls(d, chunk):
     """core.encode_topk (seen bitmap of a chunk built on a side stream while the chunk is encoded, several chunks
     through one workspace) returns exactly what encode() followed by score_topk() returns."""
