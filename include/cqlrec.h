@@ -10,7 +10,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc'd / a torch tensor's data_ptr()) unless marked [host];
  *   - plain pointers and sizes only, no torch types; `stream` is a hipStream_t passed as void* (0 = null stream);
- *   - all calls are asynchronous on `stream`, allocate nothing, never synchronise: they may be captured in a hipGraph;
+ *   - all calls are asynchronous on `stream`, allocate nothing, never synchronise: they may be captured in a hipGraph
+ *     (after one warm-up call: kernels with > 64 KiB of dynamic LDS opt in on first use; tests/test_gpu_kernels.py
+ *     ::test_entry_points_capture_in_a_hip_graph).  The step drivers take the step number by value -- sampling seed and
+ *     Adam bias corrections are baked into their launches -- so a captured training step replays THAT step;
  *   - bf16 tensors are uint16_t bit patterns; matrices are row-major; W1/W2 are stored [out][in];
  *   - return value: CQLREC_OK, or a negative code with the message available from cqlrec_last_error();
  *   - the kernel-level entry points are re-entrant; the step driver (cqlrec_train_step*) keeps one set of internal
