@@ -40,6 +40,9 @@ __device__ __forceinline__ void qf2_mfma_y(f32x16& y, const bf16x8& a_frag, cons
 }
 #endif
 
+#ifdef QF2_PROBE_PSTORE
+__device__ uint32_t* qf2_probe_p_dev;      // timing-only probe buffer (cql_qfwd2_run allocates it)
+#endif
 template <int D>
 __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
   using C = DeCfg<D, 4>;
@@ -55,6 +58,9 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
   const int64_t s_begin = (int64_t)split * a.split_rows;
   const int64_t s_end = (s_begin + a.split_rows < a.n_items) ? (s_begin + a.split_rows) : a.n_items;
   const int nst = (s_end > s_begin) ? (int)((s_end - s_begin + C::TI - 1) / C::TI) : 0;
+#ifdef QF2_PROBE_PSTORE
+  uint32_t* const probe_p = qf2_probe_p_dev;
+#endif
   if (nst <= 0) return;
   const uint32_t gst0 = (uint32_t)(s_begin / C::TI);
 
@@ -295,6 +301,16 @@ __global__ __launch_bounds__(256, 1) void qfwd2_kernel(QFwd2Args a) {
     cs[1] += csum_total(c1);
     dpa = pa1;
     dpb = frag(pw1, 1);
+#ifdef QF2_PROBE_PSTORE      // timing-only probe: what does it cost this kernel to write its P tiles out?
+    {                        // 2 groups x 32 B per lane and tile, as four 1 KiB wave stores into a per-wave stream
+      const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * (2 * nst) + 2 * st + decltype(IT)::value;
+      uint32_t* dst = probe_p + tile * 1024 + lane * 4;
+      *reinterpret_cast<u32x4*>(dst) = u32x4{pw0[0], pw0[1], pw0[2], pw0[3]};
+      *reinterpret_cast<u32x4*>(dst + 256) = u32x4{pw0[4], pw0[5], pw0[6], pw0[7]};
+      *reinterpret_cast<u32x4*>(dst + 512) = u32x4{pw1[0], pw1[1], pw1[2], pw1[3]};
+      *reinterpret_cast<u32x4*>(dst + 768) = u32x4{pw1[4], pw1[5], pw1[6], pw1[7]};
+    }
+#endif
   };
 
 #pragma unroll
@@ -399,6 +415,19 @@ bool cql_qfwd2_supported(int d, int64_t n_items) {
 
 int cql_qfwd2_run(const QFwd2Args& a, int d, hipStream_t s) {
   if (!cql_qfwd2_supported(d, a.n_items)) return CQLREC_ERR_INVALID;
+#ifdef QF2_PROBE_PSTORE
+  {
+    static void* buf = nullptr;
+    static int64_t cap = 0;
+    const int64_t need = ((a.n_states + 255) / 256 * 256) * ((a.n_items + 63) / 64 * 64 + 64 * a.nsplit) * 2 + (1 << 20);
+    if (need > cap) {
+      if (buf) (void)hipFree(buf);
+      if (hipMalloc(&buf, (size_t)need) != hipSuccess) return CQLREC_ERR_HIP;
+      cap = need;
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(qf2_probe_p_dev), &buf, sizeof(buf));
+    }
+  }
+#endif
   constexpr int smem = 2 * DeCfg<128, 4>::BUF_BYTES;
   const int64_t rblks = (a.n_states + 255) / 256;
   hipLaunchKernelGGL((qfwd2_kernel<128>), dim3((unsigned)(rblks * a.nsplit)), dim3(256), smem, s, a);
