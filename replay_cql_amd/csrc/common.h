@@ -59,7 +59,7 @@ int64_t cql_onehot_ws_bytes(int64_t batch, int32_t d);
 int cql_onehot_prepare(const int32_t* act, int64_t batch, int64_t n_items, int32_t d, void* ws, int64_t ws_bytes,
                        hipStream_t s);
 int cql_onehot_apply(const float* coef, const uint16_t* H_b, int64_t batch, int64_t n_items, int32_t d, void* ws,
-                     float* g_E_out, float* g_b_out, hipStream_t s);
+                     float* g_E_out, float* g_b_out, hipStream_t s, int accumulate = 0);
 
 static inline int cql_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void segsum_pass1_kernel(const void* __restric
                                                            const uint32_t* __restrict__ vals, int64_t n_pairs,
                                                            uint32_t pad_key, float* __restrict__ dst,
                                                            float* __restrict__ dst_w, float* __restrict__ edge,
-                                                           float* __restrict__ edge_w) {
+                                                           float* __restrict__ edge_w, int accumulate) {
   constexpr int PER = D / 64;
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256) void segsum_pass1_kernel(const void* __restric
     if (open_left) { row = edge + (chunk * 2 + 0) * D; if (SRC_BF16) roww = edge_w + chunk * 2 + 0; }
     else if (open_right) { row = edge + (chunk * 2 + 1) * D; if (SRC_BF16) roww = edge_w + chunk * 2 + 1; }
     else { row = dst + (int64_t)run_key * D; if (SRC_BF16) roww = dst_w + run_key; }
+    const bool add = accumulate && row != edge + (chunk * 2 + 0) * D && row != edge + (chunk * 2 + 1) * D;   // rows of dst only
 #pragma unroll
-    for (int k = 0; k < PER; ++k) row[k * 64 + lane] = acc[k];
-    if (SRC_BF16 && lane == 0) *roww = accw;
+    for (int k = 0; k < PER; ++k) row[k * 64 + lane] = add ? row[k * 64 + lane] + acc[k] : acc[k];
+    if (SRC_BF16 && lane == 0) *roww = add ? *roww + accw : accw;
   };
 #pragma unroll 8
   for (int j = 0; j < CH; ++j) {
@@ -129,7 +130,7 @@ template <int D, bool SRC_BF16, int CH>
 __global__ __launch_bounds__(256) void segsum_pass2_kernel(const uint32_t* __restrict__ keys, int64_t n_pairs,
                                                            uint32_t pad_key, const float* __restrict__ edge,
                                                            const float* __restrict__ edge_w, float* __restrict__ dst,
-                                                           float* __restrict__ dst_w) {
+                                                           float* __restrict__ dst_w, int accumulate) {
   constexpr int PER = D / 64;
   const int lane = threadIdx.x & 63;
   const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -158,17 +159,21 @@ __global__ __launch_bounds__(256) void segsum_pass2_kernel(const uint32_t* __res
     if (SRC_BF16) accw += edge_w[j * 2 + 0];
   }
 #pragma unroll
-  for (int q = 0; q < PER; ++q) dst[(int64_t)k * D + q * 64 + lane] = acc[q];
-  if (SRC_BF16 && lane == 0) dst_w[k] = accw;
+  for (int q = 0; q < PER; ++q) {
+    float* o = dst + (int64_t)k * D + q * 64 + lane;
+    *o = accumulate ? *o + acc[q] : acc[q];
+  }
+  if (SRC_BF16 && lane == 0) dst_w[k] = accumulate ? dst_w[k] + accw : accw;
 }
 
 // host side of the two passes
 template <bool SRC_BF16, int CH>
 static void segsum_launch(const void* src, const float* w, const uint32_t* keys, const uint32_t* vals, int64_t n_pairs,
-                          uint32_t pad_key, int d, float* dst, float* dst_w, float* edge, float* edge_w, hipStream_t s) {
+                          uint32_t pad_key, int d, float* dst, float* dst_w, float* edge, float* edge_w, hipStream_t s,
+                          int accumulate = 0) {
   dim3 grid(cql_ceil_div((n_pairs + CH - 1) / CH, 4)), block(256);
-#define SS1(DD) hipLaunchKernelGGL((segsum_pass1_kernel<DD, SRC_BF16, CH>), grid, block, 0, s, src, w, keys, vals, n_pairs, pad_key, dst, dst_w, edge, edge_w)
-#define SS2(DD) hipLaunchKernelGGL((segsum_pass2_kernel<DD, SRC_BF16, CH>), grid, block, 0, s, keys, n_pairs, pad_key, edge, edge_w, dst, dst_w)
+#define SS1(DD) hipLaunchKernelGGL((segsum_pass1_kernel<DD, SRC_BF16, CH>), grid, block, 0, s, src, w, keys, vals, n_pairs, pad_key, dst, dst_w, edge, edge_w, accumulate)
+#define SS2(DD) hipLaunchKernelGGL((segsum_pass2_kernel<DD, SRC_BF16, CH>), grid, block, 0, s, keys, n_pairs, pad_key, edge, edge_w, dst, dst_w, accumulate)
   if (d == 64) { SS1(64); SS2(64); } else if (d == 128) { SS1(128); SS2(128); } else { SS1(256); SS2(256); }
 #undef SS1
 #undef SS2
@@ -347,13 +352,14 @@ int cql_onehot_prepare(const int32_t* act, int64_t batch, int64_t n_items, int32
   return CQLREC_OK;
 }
 
-// g_E_out / g_b_out rows of the sampled actions must be zero on entry (they are written, not added to)
+// accumulate = 0: g_E_out / g_b_out rows of the sampled actions must be zero on entry (they are written, not added to);
+// accumulate = 1: the sum of an action's run is ADDED to what its row holds (row + sum, once per row)
 int cql_onehot_apply(const float* coef, const uint16_t* H_b, int64_t batch, int64_t n_items, int32_t d, void* ws,
-                     float* g_E_out, float* g_b_out, hipStream_t s) {
+                     float* g_E_out, float* g_b_out, hipStream_t s, int accumulate) {
   CQL_REQUIRE(coef && H_b && ws && g_E_out && g_b_out, "onehot_apply: NULL pointer");
   const OhWs w = oh_carve(ws, batch, d);
   CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
-  segsum_launch<true, OH_CH>(H_b, coef, w.keys_out, w.vals_out, batch, (uint32_t)n_items, d, g_E_out, g_b_out, w.edge, w.edge_w, s);
+  segsum_launch<true, OH_CH>(H_b, coef, w.keys_out, w.vals_out, batch, (uint32_t)n_items, d, g_E_out, g_b_out, w.edge, w.edge_w, s, accumulate);
   CQL_LAUNCH_CHECK("onehot_apply");
   return CQLREC_OK;
 }

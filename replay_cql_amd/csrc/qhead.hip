@@ -1156,6 +1156,14 @@ extern "C" int cqlrec_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_it
   return cql_qhead_dh_finish(ws, rows, n_items, d, lse, coef, act, E_out_b, scale, dH, (hipStream_t)stream);
 }
 
+int cql_qhead_bwd_items_long(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
+                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
+                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, CqlAdamFix* defer,
+                             const float* nlse_nat) {
+  return qhead_bwd_items_impl(H_b, nlse2, coef, act, batch, E_out_b, b_out, n_items, d, scale, ws, ws_bytes, g_E_out,
+                              g_b_out, (cqlrec_stream)stream, false, false, 0, -1, defer, nlse_nat);
+}
+
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, int do_sparse,

@@ -486,3 +486,25 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
   }
   return CQLREC_OK;
 }
+
+// the fix-up launch for a descriptor cql_qde_launch filled instead of launching it (a caller that has something to add to
+// the rows between the long kernel and the slabs: the one-hot part, see train.hip)
+int cql_qde_fixup_deferred(const CqlAdamFix& f, float* out, float* out_cs, hipStream_t s) {
+  if (!f.valid) return CQLREC_OK;
+  QDeArgs a = {};
+  a.n_items = f.n_items;
+  a.out = out;
+  a.out_cs = out_cs;
+  a.scale = f.scale;
+  a.slab = const_cast<float*>(f.slab);
+  a.slab_cs = const_cast<float*>(f.slab_cs);
+  a.G = f.G;
+  a.T = f.T;
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  const int waves = f.items / 32;
+  if (f.D == 64) qde_fixup_d<64>(a, f.nblk, waves, s);
+  else if (f.D == 128) qde_fixup_d<128>(a, f.nblk, waves, s);
+  else qde_fixup_d<256>(a, f.nblk, waves, s);
+  CQL_LAUNCH_CHECK("qde fix-up");
+  return CQLREC_OK;
+}

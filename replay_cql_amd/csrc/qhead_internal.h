@@ -91,6 +91,14 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
                    int64_t n_items, int32_t d, float scale, void* ws, int64_t ws_bytes, float* out, float* out_cs,
                    int accumulate, hipStream_t s, CqlAdamFix* defer = nullptr, const float* nlse_nat = nullptr);
 
+int cql_qde_fixup_deferred(const CqlAdamFix& f, float* out, float* out_cs, hipStream_t s);
+// the long item-side kernel alone: rows WRITTEN (out = scale * dE, nothing read), no one-hot part; cut pieces left to
+// `defer` (cql_qde_fixup_deferred / cql_adam_ema_fix) when the shape takes the stream-K kernels, else complete
+int cql_qhead_bwd_items_long(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
+                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,
+                             int64_t ws_bytes, float* g_E_out, float* g_b_out, hipStream_t stream, CqlAdamFix* defer,
+                             const float* nlse_nat);
+
 // qhead_topk2.hip: the top-K pass as a one-wave-per-SIMD kernel with on-chip selection (d = 128, k <= 16, whole catalogue)
 struct QTk2Args {
   const uint16_t* H_b;          // [n_users x D] bf16 state vectors

@@ -160,7 +160,7 @@ struct SideStream {
   hipStream_t s3 = nullptr;   // sampling + sorts of the NEXT step (cqlrec_train_steps)
   hipEvent_t sorted[2] = {nullptr, nullptr};   // sorted pairs of the step with this parity are in place
   hipEvent_t forked = nullptr, fork2 = nullptr, join2 = nullptr;
-  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr, bpro = nullptr;
+  hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr, bpro = nullptr, fwd_done = nullptr;
   bool ok = false;
   bool tried = false;
 };
@@ -194,7 +194,8 @@ SideStream& side_stream() {
             hipEventCreateWithFlags(&ss.eout, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.presample, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.adam_in, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.bpro, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ss.bpro, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fwd_done, hipEventDisableTiming) == hipSuccess;
   }
   return ss;
 }
@@ -253,8 +254,11 @@ int sample_ahead(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream,
   return cql_onehot_prepare(w.act, c->batch, L.n_items, L.d, w.ws_oh, w.ws_oh_bytes, (hipStream_t)stream);
 }
 
+int backward_items_long_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, CqlAdamFix* fix);
+// early_items (a stream) + early_fix: the long item-side kernel of THIS step is launched on that stream as soon as the fused
+// forward has produced -lse (it needs nothing from the loss), see backward_items_impl
 int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlrec_stream stream, hipEvent_t eout_ready,
-                 hipEvent_t presampled = nullptr) {
+                 hipEvent_t presampled = nullptr, hipStream_t early_items = nullptr, CqlAdamFix* early_fix = nullptr) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d, W = c->window;
   const int64_t N = L.n_items;
@@ -323,6 +327,11 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   // logsumexp AND the softmax-weighted sum of item rows (the soft part of dH) in ONE pass over the catalogue
   CQL_TRY(cql_qhead_fwd_lse_dh(w.hb, B, p.Eout_b, p.b_out, N, d, w.ws_qb, w.ws_qf_bytes, w.lse, w.nlse2, s, w.nlse_nat, 1));
   if (g_mark_phase == 2) mark(MK_LSE, s);
+  if (early_items) {
+    CQL_HIP_TRY(hipEventRecord(ss.fwd_done, s), "train_step_forward");
+    CQL_HIP_TRY(hipStreamWaitEvent(early_items, ss.fwd_done, 0), "train_step_forward");
+    CQL_TRY(backward_items_long_impl(c, step, (cqlrec_stream)early_items, early_fix));
+  }
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
   if (!corun) CQL_TRY(branch_b_prologue());
@@ -345,23 +354,53 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   return CQLREC_OK;
 }
 
-// item-side backward.  ctx->grads is zero on entry (contract of the step).
-int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, CqlAdamFix* defer = nullptr) {
+// item-side backward.  ctx->grads is zero on entry (contract of the step).  Three parts, the sum of a gradient row formed in
+// ONE order on every path (pipelined, phased, strict) so that they stay bit-identical:
+//   row = ((scale * dE piece holding stage 0) + one-hot part) + scale * cut pieces, in block order
+// (1) the long kernel WRITES its rows (nothing to read, nothing to wait for but the forward's -lse: the pipelined driver
+//     launches it as soon as the fused forward has finished, under the rest of the forward and the loss),
+// (2) the one-hot part -- the only part that needs the loss's coefficients -- is added as a segmented sum,
+// (3) the cut pieces: fix-up launch here, or left to the item-side optimizer (CqlAdamFix).
+static bool onehot_atomic() {
+  static const bool v = getenv("CQL_ONEHOT_ATOMIC") && getenv("CQL_ONEHOT_ATOMIC")[0] == '1';   // A/B knob: old order, float atomics
+  return v;
+}
+int backward_items_long_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, CqlAdamFix* fix) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d;
   StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
+  return cql_qhead_bwd_items_long(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, alpha_scale(c), w.ws_qb2,
+                                  w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out, (hipStream_t)stream, fix,
+                                  w.nlse_nat);
+}
+int backward_items_onehot_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
+  const cqlrec_layout& L = c->layout;
+  const int32_t B = c->batch, d = L.d;
+  StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
   SideStream& ss = side_stream();
   // the (action, transition) pairs were sorted ahead of time on another stream (same event as the window pairs)
   if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.sorted[step & 1], 0), "train_step_backward_items");
-  // one-hot part first, as a deterministic segmented sum into the zeroed gradient rows; the long kernel accumulates
-  static const bool atomic_scatter = getenv("CQL_ONEHOT_ATOMIC") && getenv("CQL_ONEHOT_ATOMIC")[0] == '1';   // A/B knob
-  if (!atomic_scatter)
-    CQL_TRY(cql_onehot_apply(w.coef, w.hb, B, L.n_items, d, w.ws_oh, c->grads + L.off_E_out, c->grads + L.off_b_out,
-                             (hipStream_t)stream));
-  return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, alpha_scale(c),
-                                 w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
-                                 (hipStream_t)stream, atomic_scatter ? 1 : 0, 0, -1, defer, w.nlse_nat);
+  return cql_onehot_apply(w.coef, w.hb, B, L.n_items, d, w.ws_oh, c->grads + L.off_E_out, c->grads + L.off_b_out,
+                          (hipStream_t)stream, 1);
+}
+// all three in program order; defer: leave (3) to the caller's optimizer launch
+int backward_items_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, CqlAdamFix* defer = nullptr) {
+  const cqlrec_layout& L = c->layout;
+  if (onehot_atomic()) {
+    const int32_t B = c->batch, d = L.d;
+    StepWs w = carve_step(c->ws, B, L.n_items, d, c->window, step);
+    const StepPtrs p = step_ptrs(c);
+    return cql_qhead_bwd_items_acc(w.hb, w.nlse2, w.coef, w.act, B, p.Eout_b, p.b_out, L.n_items, d, alpha_scale(c),
+                                   w.ws_qb2, w.ws_qb_bytes, c->grads + L.off_E_out, c->grads + L.off_b_out,
+                                   (hipStream_t)stream, 1, 0, -1, defer, w.nlse_nat);
+  }
+  CqlAdamFix fix = {};
+  CQL_TRY(backward_items_long_impl(c, step, stream, &fix));
+  CQL_TRY(backward_items_onehot_impl(c, step, stream));
+  if (defer) *defer = fix;
+  else CQL_TRY(cql_qde_fixup_deferred(fix, c->grads + L.off_E_out, c->grads + L.off_b_out, (hipStream_t)stream));
+  return CQLREC_OK;
 }
 
 // records `dh` behind dh_finish, the last reader of the E_out shadow on this stream: the item-side Adam waits for it
@@ -464,7 +503,12 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
   need_side_streams(side_stream(), true);
   for (int32_t i = 0; i < n_steps; ++i) {
     const uint64_t step = step0 + (uint64_t)i;
-    CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled));
+    // CQL_EARLY_DE=0: the long item-side kernel behind the loss (A/B knob); default: behind the fused forward
+    static const int early_de = !(getenv("CQL_EARLY_DE") && getenv("CQL_EARLY_DE")[0] == '0');
+    SideStream& ss0 = side_stream();
+    const bool early = early_de && ss0.ok && ss0.s && !onehot_atomic();
+    CqlAdamFix fix = {};
+    CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled, early ? ss0.s : nullptr, &fix));
     pending = sampled = nullptr;
     if (g_marks_on && n_steps >= 4) {   // marks: backward of step n/2, forward of step n/2 + 1
       if (i == n_steps / 2) g_mark_phase = 1;
@@ -483,8 +527,15 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
       CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.loss, 0), "train_steps");
       // sparse scatter, then the long dE_out kernel; the sum of its cut pieces is left to the item-side Adam below
       static const int defer_fixup = !(getenv("CQL_DEFER_FIXUP") && getenv("CQL_DEFER_FIXUP")[0] == '0');
-      CqlAdamFix fix = {};
-      CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s, defer_fixup ? &fix : nullptr));
+      if (early) {          // the long kernel is running (or done) already: the one-hot part on top, cut pieces as asked
+        CQL_TRY(backward_items_onehot_impl(c, step, (cqlrec_stream)ss.s));
+        if (!defer_fixup) {
+          CQL_TRY(cql_qde_fixup_deferred(fix, c->grads + L.off_E_out, c->grads + L.off_b_out, ss.s));
+          fix.valid = 0;
+        }
+      } else {
+        CQL_TRY(backward_items_impl(c, step, (cqlrec_stream)ss.s, defer_fixup ? &fix : nullptr));
+      }
       if (g_mark_phase == 1) mark(MK_DE, ss.s);
       CQL_TRY(backward_states_impl(c, step, stream));                      // dh_finish, records ss.dh
       if (g_mark_phase == 1) mark(MK_DH, s);
