@@ -55,6 +55,9 @@ struct CqlProfScope {
 };
 
 // deterministic one-hot scatter of the Q-head backward (gbwd.hip): sort of (act[b], b) ahead of time, then a segmented sum
+int cql_encoder_bwd_parts(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,
+                          const uint16_t* W2_b, int64_t rows, int32_t d, void* ws, int64_t ws_bytes, float* g_W1, float* g_b1,
+                          float* g_W2, float* g_b2, float* dh0, int parts, hipStream_t s);
 int64_t cql_onehot_ws_bytes(int64_t batch, int32_t d);
 int cql_onehot_prepare(const int32_t* act, int64_t batch, int64_t n_items, int32_t d, void* ws, int64_t ws_bytes,
                        hipStream_t s);

@@ -484,10 +484,21 @@ extern "C" int64_t cqlrec_encoder_bwd_ws_bytes(int64_t rows, int32_t d) {
   return (rows * d + 2 * nchunk * d * d + 2 * nchunk * d) * (int64_t)sizeof(float) + 256;
 }
 
+// parts: 1 = the input-side products (dA1 into ws, dh0: what the window-gather backward waits for), 2 = the weight / bias
+// gradients (read dA1: behind part 1), 3 = both in order.  The step driver runs part 2 on another stream.
+int cql_encoder_bwd_parts(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,
+                          const uint16_t* W2_b, int64_t rows, int32_t d, void* ws, int64_t ws_bytes, float* g_W1, float* g_b1,
+                          float* g_W2, float* g_b2, float* dh0, int parts, hipStream_t s);
 extern "C" int cqlrec_encoder_bwd(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,
                                   const uint16_t* W2_b, int64_t rows, int32_t d, void* ws, int64_t ws_bytes,
                                   float* g_W1, float* g_b1, float* g_W2, float* g_b2, float* dh0,
                                   cqlrec_stream stream) {
+  return cql_encoder_bwd_parts(dH, z_b, h0_b, W1_b, W2_b, rows, d, ws, ws_bytes, g_W1, g_b1, g_W2, g_b2, dh0, 3,
+                               (hipStream_t)stream);
+}
+int cql_encoder_bwd_parts(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,
+                          const uint16_t* W2_b, int64_t rows, int32_t d, void* ws, int64_t ws_bytes, float* g_W1, float* g_b1,
+                          float* g_W2, float* g_b2, float* dh0, int parts, hipStream_t stream) {
   CQL_REQUIRE(dH && z_b && h0_b && W1_b && W2_b && ws && g_W1 && g_b1 && g_W2 && g_b2 && dh0, "encoder_bwd: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "encoder_bwd: d=%d unsupported", d);
   CQL_REQUIRE(rows > 0, "encoder_bwd: rows=%lld", (long long)rows);
@@ -500,12 +511,15 @@ extern "C" int cqlrec_encoder_bwd(const float* dH, const uint16_t* z_b, const ui
   CqlProfScope prof(CQLREC_PH_ENCODER_BWD, s);
 #define ENC_LAUNCH(DD)                                                                                               \
   do {                                                                                                               \
-    hipLaunchKernelGGL(enc_bwd_dx_kernel<DD>, dim3(cql_ceil_div(rows, 32)), dim3(256), 0, s, dH, z_b, W1_b, W2_b,   \
-                       rows, dA1, dh0);                                                                              \
-    hipLaunchKernelGGL(enc_bwd_dw_kernel<DD>, dim3((DD / 32) * (DD / 32) / 4, nchunk, 2), dim3(256), 0, s, dH, dA1, z_b, \
-                       h0_b, rows, slab_w, slab_b, nchunk);                                                          \
-    hipLaunchKernelGGL(enc_bwd_reduce_kernel<DD>, dim3(cql_ceil_div(DD * DD, 256), 2), dim3(256), 0, s, slab_w,      \
-                       slab_b, nchunk, g_W1, g_b1, g_W2, g_b2);                                                      \
+    if (parts & 1)                                                                                                   \
+      hipLaunchKernelGGL(enc_bwd_dx_kernel<DD>, dim3(cql_ceil_div(rows, 32)), dim3(256), 0, s, dH, z_b, W1_b, W2_b, \
+                         rows, dA1, dh0);                                                                            \
+    if (parts & 2) {                                                                                                 \
+      hipLaunchKernelGGL(enc_bwd_dw_kernel<DD>, dim3((DD / 32) * (DD / 32) / 4, nchunk, 2), dim3(256), 0, s, dH, dA1, z_b, \
+                         h0_b, rows, slab_w, slab_b, nchunk);                                                        \
+      hipLaunchKernelGGL(enc_bwd_reduce_kernel<DD>, dim3(cql_ceil_div(DD * DD, 256), 2), dim3(256), 0, s, slab_w,    \
+                         slab_b, nchunk, g_W1, g_b1, g_W2, g_b2);                                                    \
+    }                                                                                                                \
   } while (0)
   if (d == 64) ENC_LAUNCH(64); else if (d == 128) ENC_LAUNCH(128); else ENC_LAUNCH(256);
 #undef ENC_LAUNCH

@@ -425,11 +425,24 @@ int backward_chain_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
   const int64_t N = L.n_items;
   StepWs w = carve_step(c->ws, B, N, d, W, step);
   const StepPtrs p = step_ptrs(c);
-  CQL_TRY(cqlrec_encoder_bwd(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
-                             c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, stream));
+  // The window-gather backward needs dh0 only: the weight / bias gradients of the encoder (two launches reading dA1) go
+  // to the branch stream, idle in the backward, and join before this function returns.  CQL_ENC_SPLIT=0: in line.
   SideStream& ss = side_stream();
-  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ss.sorted[step & 1], 0), "train_step_backward_rest");
+  hipStream_t s = (hipStream_t)stream;
+  static const int enc_split = !(getenv("CQL_ENC_SPLIT") && getenv("CQL_ENC_SPLIT")[0] == '0');
+  const bool split = enc_split && ss.ok && ss.s2 && ss.s2 != s;
+  CQL_TRY(cql_encoder_bwd_parts(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
+                                c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, split ? 1 : 3, s));
+  if (split) {
+    CQL_HIP_TRY(hipEventRecord(ss.fork2, s), "train_step_backward_rest");
+    CQL_HIP_TRY(hipStreamWaitEvent(ss.s2, ss.fork2, 0), "train_step_backward_rest");
+    CQL_TRY(cql_encoder_bwd_parts(w.dH, w.zb, w.h0b, p.W1_b, p.W2_b, B, d, w.ws_enc, w.ws_enc_bytes, c->grads + L.off_W1,
+                                  c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, 2, ss.s2));
+    CQL_HIP_TRY(hipEventRecord(ss.join2, ss.s2), "train_step_backward_rest");
+  }
+  if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.sorted[step & 1], 0), "train_step_backward_rest");
   CQL_TRY(cqlrec_gather_pool_bwd_apply(w.dh0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, c->grads + L.off_E_in, stream));
+  if (split) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.join2, 0), "train_step_backward_rest");
   return CQLREC_OK;
 }
 
