@@ -99,6 +99,10 @@ int cqlrec_gather_pool_bwd_sorted(const float* dh0, const int64_t* offsets, cons
  * --------------------------------------------------------------------------------------------------------- */
 int cqlrec_linear_bf16(const uint16_t* X_b, const uint16_t* W_b, const float* bias, int64_t rows, int32_t d,
                        int32_t relu, float* Y, uint16_t* Y_b, cqlrec_stream stream);
+/* Both layers of the state encoder in one launch:  Z_b = bf16(relu(X_b W1_b^T + b1)),  H_b = bf16(Z_b W2_b^T + b2) -- the
+ * bits of two cqlrec_linear_bf16 calls (same products, same k-order, same roundings); Z_b is kept for the backward. */
+int cqlrec_encoder_fwd(const uint16_t* X_b, const uint16_t* W1_b, const float* b1, const uint16_t* W2_b, const float* b2,
+                       int64_t rows, int32_t d, uint16_t* Z_b, uint16_t* H_b, cqlrec_stream stream);
 /* fp32 backward of the two-layer encoder on the bf16-valued forward operands.  ws: cqlrec_encoder_bwd_ws_bytes. */
 int64_t cqlrec_encoder_bwd_ws_bytes(int64_t rows, int32_t d);
 int cqlrec_encoder_bwd(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "cqlrec_gather_pool_bwd_apply": (i32, [vp, i64, i32, i32, i64, vp, i64, vp, vp]),
     "cqlrec_gather_pool_bwd_sorted": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i64, vp, i64, vp, vp]),
     "cqlrec_linear_bf16": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
+    "cqlrec_encoder_fwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp]),
     "cqlrec_encoder_bwd_ws_bytes": (i64, [i64, i32]),
     "cqlrec_encoder_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp]),
     "cqlrec_qhead_ws_bytes": (i64, [i64, i64, i32]),

@@ -334,6 +334,84 @@ __global__ __launch_bounds__(64) void linear_bf16_kernel(const uint16_t* __restr
   }
 }
 
+// Both encoder layers in one launch: z = relu(X W1^T + b1) (bf16, kept: the backward reads it), h = z W2^T + b2 (bf16).  The
+// products, their k-order and the roundings are those of two linear_bf16_kernel launches -- the bf16 z tile of the block's
+// 32 rows goes through LDS (accumulator layout -> operand layout) instead of through memory and a second launch.
+template <int D>
+__global__ __launch_bounds__(64) void encoder_fwd_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1,
+                                                         const float* __restrict__ b1, const uint16_t* __restrict__ W2,
+                                                         const float* __restrict__ b2, int64_t rows,
+                                                         uint16_t* __restrict__ Zb, uint16_t* __restrict__ Hb) {
+  constexpr int KS = D / 16;
+  constexpr int LDZ = D + 8;                       // row stride of the z tile in bf16 (16-byte aligned rows, skewed banks)
+  __shared__ __attribute__((aligned(16))) uint16_t zt[32 * LDZ];
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  int64_t mrow = m0 + r;
+  if (mrow >= rows) mrow = rows - 1;
+  bf16x8 xf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(X + mrow * D + 16 * s + 8 * h);
+#pragma unroll 1
+  for (int ot = 0; ot < D / 32; ++ot) {
+    const int o = ot * 32 + r;
+    const float bo = b1[o];
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bo;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 wf = *reinterpret_cast<const bf16x8*>(W1 + (int64_t)o * D + 16 * s + 8 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[s], wf, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mr = mfma_row(i, h);
+      const uint16_t zb = f32_to_bf16_bits(fmaxf(acc[i], 0.f));
+      zt[mr * LDZ + o] = zb;
+      if (m0 + mr < rows) Zb[(m0 + mr) * D + o] = zb;
+    }
+  }
+  __syncthreads();                                 // one wave: orders the LDS writes above before the reads below
+  bf16x8 zf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) zf[s] = *reinterpret_cast<const bf16x8*>(zt + r * LDZ + 16 * s + 8 * h);
+#pragma unroll 1
+  for (int ot = 0; ot < D / 32; ++ot) {
+    const int o = ot * 32 + r;
+    const float bo = b2[o];
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bo;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 wf = *reinterpret_cast<const bf16x8*>(W2 + (int64_t)o * D + 16 * s + 8 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[s], wf, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t m = m0 + mfma_row(i, h);
+      if (m < rows) Hb[m * D + o] = f32_to_bf16_bits(acc[i]);
+    }
+  }
+}
+
+extern "C" int cqlrec_encoder_fwd(const uint16_t* X_b, const uint16_t* W1_b, const float* b1, const uint16_t* W2_b,
+                                  const float* b2, int64_t rows, int32_t d, uint16_t* Z_b, uint16_t* H_b,
+                                  cqlrec_stream stream) {
+  CQL_REQUIRE(X_b && W1_b && b1 && W2_b && b2 && Z_b && H_b, "encoder_fwd: NULL pointer");
+  CQL_REQUIRE(d == 64 || d == 128 || d == 256, "encoder_fwd: d=%d unsupported", d);
+  if (rows <= 0) return CQLREC_OK;
+  dim3 grid(cql_ceil_div(rows, 32)), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  CqlProfScope prof(CQLREC_PH_ENCODER_FWD, s);
+#define ENCF_LAUNCH(DD) hipLaunchKernelGGL(encoder_fwd_kernel<DD>, grid, block, 0, s, X_b, W1_b, b1, W2_b, b2, rows, Z_b, H_b)
+  if (d == 64) ENCF_LAUNCH(64); else if (d == 128) ENCF_LAUNCH(128); else ENCF_LAUNCH(256);
+#undef ENCF_LAUNCH
+  CQL_LAUNCH_CHECK("encoder_fwd");
+  return CQLREC_OK;
+}
+
 extern "C" int cqlrec_linear_bf16(const uint16_t* X_b, const uint16_t* W_b, const float* bias, int64_t rows, int32_t d,
                                   int32_t relu, float* Y, uint16_t* Y_b, cqlrec_stream stream) {
   CQL_REQUIRE(X_b && W_b && bias, "linear_bf16: NULL pointer");

@@ -306,10 +306,8 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   auto branch_b_prologue = [&]() -> int {
     CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b + Bd, nullptr, sb));
     CQL_TRY(cqlrec_gather_pool_fwd(p.tEin_b, c->offsets, c->items, w.users, w.tpos, 1, B, W, d, nullptr, w.h0b_t, nullptr, sb));
-    CQL_TRY(cqlrec_linear_bf16(w.h0b + Bd, p.W1_b, p.b1, B, d, 1, nullptr, w.zb + Bd, sb));
-    CQL_TRY(cqlrec_linear_bf16(w.zb + Bd, p.W2_b, p.b2, B, d, 0, nullptr, w.hb + Bd, sb));
-    CQL_TRY(cqlrec_linear_bf16(w.h0b_t, p.tW1_b, p.tb1, B, d, 1, nullptr, w.zb_t, sb));
-    CQL_TRY(cqlrec_linear_bf16(w.zb_t, p.tW2_b, p.tb2, B, d, 0, nullptr, w.hb_t, sb));
+    CQL_TRY(cqlrec_encoder_fwd(w.h0b + Bd, p.W1_b, p.b1, p.W2_b, p.b2, B, d, w.zb + Bd, w.hb + Bd, sb));
+    CQL_TRY(cqlrec_encoder_fwd(w.h0b_t, p.tW1_b, p.tb1, p.tW2_b, p.tb2, B, d, w.zb_t, w.hb_t, sb));
     return CQLREC_OK;
   };
   if (corun) {
@@ -318,8 +316,7 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   }
   // ---- branch A
   CQL_TRY(cqlrec_gather_pool_fwd(p.Ein_b, c->offsets, c->items, w.users, w.tpos, 0, B, W, d, w.h0_s, w.h0b, nullptr, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.h0b, p.W1_b, p.b1, B, d, 1, nullptr, w.zb, stream));
-  CQL_TRY(cqlrec_linear_bf16(w.zb, p.W2_b, p.b2, B, d, 0, nullptr, w.hb, stream));
+  CQL_TRY(cqlrec_encoder_fwd(w.h0b, p.W1_b, p.b1, p.W2_b, p.b2, B, d, w.zb, w.hb, stream));
   if (g_mark_phase == 2) mark(MK_PROLOGUE, s);
   CQL_TRY(cql_qhead_fwd_lse_dh_prepare(w.ws_qb, B, N, d, s));      // (a 4-byte memset: in front of the wait, not behind it)
   if (eout_ready) CQL_HIP_TRY(hipStreamWaitEvent(s, eout_ready, 0), "train_step_forward");

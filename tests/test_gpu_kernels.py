@@ -178,6 +178,27 @@ def test_linear_bf16(lib, d, rows):
 
 
 @pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("rows", [1, 45, 4096 + 7])
+def test_encoder_fwd_fused_equals_two_layers(lib, d, rows):
+    """cqlrec_encoder_fwd (both layers in one launch, the hidden tile through LDS) gives the bits of two
+    cqlrec_linear_bf16 calls -- hidden and output, random data -- and those are the oracle's roundings."""
+    rng = np.random.default_rng(3 * d + rows)
+    Xb = bf16_dev(O.bf16_round(rng.standard_normal((rows, d)).astype(np.float32)))
+    W1 = bf16_dev(O.bf16_round((rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)))
+    W2 = bf16_dev(O.bf16_round((rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)))
+    b1, b2 = dev(rng.standard_normal(d).astype(np.float32) * 0.1), dev(rng.standard_normal(d).astype(np.float32) * 0.1)
+    z_ref = torch.empty((rows, d), dtype=torch.bfloat16, device=DEV)
+    h_ref = torch.empty_like(z_ref)
+    N.check(lib.cqlrec_linear_bf16(ptr(Xb), ptr(W1), ptr(b1), rows, d, 1, None, ptr(z_ref), stream()))
+    N.check(lib.cqlrec_linear_bf16(ptr(z_ref), ptr(W2), ptr(b2), rows, d, 0, None, ptr(h_ref), stream()))
+    z, h = torch.full_like(z_ref, 7.0), torch.full_like(z_ref, 7.0)
+    N.check(lib.cqlrec_encoder_fwd(ptr(Xb), ptr(W1), ptr(b1), ptr(W2), ptr(b2), rows, d, ptr(z), ptr(h), stream()))
+    sync()
+    assert torch.equal(z.view(torch.int16), z_ref.view(torch.int16))
+    assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
 @pytest.mark.parametrize("rows", [37, 300])
 def test_encoder_bwd(lib, d, rows):
     rng = np.random.default_rng(7 * d + rows)
