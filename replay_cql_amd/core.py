@@ -468,8 +468,12 @@ class CQLCore:
         N.check(self.lib.cqlrec_gather_pool_fwd(eb + 2 * lay.off_E_in, _ptr(offsets), _ptr(items), _ptr(users), _ptr(ends),
                                                 end_delta, n, h.window, h.d, None, _ptr(h0b), None, s), "gather_pool_fwd")
         fp = flat.data_ptr()
-        N.check(self.lib.cqlrec_encoder_fwd(_ptr(h0b), eb + 2 * lay.off_W1, fp + 4 * lay.off_b1, eb + 2 * lay.off_W2,
-                                            fp + 4 * lay.off_b2, n, h.d, _ptr(zb), _ptr(hb), s), "encoder_fwd")
+        # two launches here, not cqlrec_encoder_fwd (same bits): in the predict pass these run on a side stream next to the
+        # seen-bitmap builder, and the one-launch form (8.5 KB of LDS per 32 rows) slowed that builder by 25 % (measured)
+        N.check(self.lib.cqlrec_linear_bf16(_ptr(h0b), eb + 2 * lay.off_W1, fp + 4 * lay.off_b1, n, h.d, 1, None,
+                                            _ptr(zb), s), "linear_bf16")
+        N.check(self.lib.cqlrec_linear_bf16(_ptr(zb), eb + 2 * lay.off_W2, fp + 4 * lay.off_b2, n, h.d, 0, None,
+                                            _ptr(hb), s), "linear_bf16")
         return hb
 
     def score_topk(self, hb: torch.Tensor, k: int, cand_items: Optional[torch.Tensor] = None,
