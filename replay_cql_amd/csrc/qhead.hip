@@ -771,7 +771,9 @@ __global__ __launch_bounds__(256) void qhead_bwd_reduce_kernel(const float* __re
 
 // dH from the fused forward's slabs:  dst[row][f] = scale * sum_k slab[k][row][f] * exp(m[k][row] - lse[row])
 //                                                  + coef[row] * E_b[act[row]][f]
-template <int D>
+// PART 0: the whole of dH.  PART 1: the soft part only (needs the forward's lse, nothing from the loss).  PART 2: the
+// one-hot term added to what PART 1 left (dst = fmaf(coef, E[a], dst)): 1 then 2 give the bits of 0.
+template <int D, int PART>
 __global__ __launch_bounds__(256) void qhead_dh_finish_kernel(const float* __restrict__ slab,
                                                               const float* __restrict__ pm, int nsplit, int64_t rows,
                                                               const float* __restrict__ lse, float scale,
@@ -784,9 +786,10 @@ __global__ __launch_bounds__(256) void qhead_dh_finish_kernel(const float* __res
   if (idx >= rows * V) return;
   const int64_t row = idx / V;
   const int c = (int)(idx % V);
-  const float nl2 = -lse[row] * CQL_LOG2E;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < nsplit; ++k) {
+  if constexpr (PART == 2) s = *reinterpret_cast<const float4*>(dst + row * D + c * 4);
+  const float nl2 = (PART == 2) ? 0.f : -lse[row] * CQL_LOG2E;
+  for (int k = 0; k < (PART == 2 ? 0 : nsplit); ++k) {
     const float mk = pm[(int64_t)k * rows + row];
     const float w = (mk == NEG_INF) ? 0.f : fast_exp2(fmaf(mk, CQL_LOG2E, nl2));
     const float4 t = *reinterpret_cast<const float4*>(slab + ((int64_t)k * rows + row) * D + c * 4);
@@ -795,16 +798,20 @@ __global__ __launch_bounds__(256) void qhead_dh_finish_kernel(const float* __res
     s.z = fmaf(w, t.z, s.z);
     s.w = fmaf(w, t.w, s.w);
   }
-  s.x *= scale;
-  s.y *= scale;
-  s.z *= scale;
-  s.w *= scale;
-  const float cf = coef[row];
-  const uint2 e = *reinterpret_cast<const uint2*>(E_b + (int64_t)act[row] * D + c * 4);
-  s.x = fmaf(cf, __uint_as_float(e.x << 16), s.x);
-  s.y = fmaf(cf, __uint_as_float(e.x & 0xFFFF0000u), s.y);
-  s.z = fmaf(cf, __uint_as_float(e.y << 16), s.z);
-  s.w = fmaf(cf, __uint_as_float(e.y & 0xFFFF0000u), s.w);
+  if constexpr (PART != 2) {
+    s.x *= scale;
+    s.y *= scale;
+    s.z *= scale;
+    s.w *= scale;
+  }
+  if constexpr (PART != 1) {
+    const float cf = coef[row];
+    const uint2 e = *reinterpret_cast<const uint2*>(E_b + (int64_t)act[row] * D + c * 4);
+    s.x = fmaf(cf, __uint_as_float(e.x << 16), s.x);
+    s.y = fmaf(cf, __uint_as_float(e.x & 0xFFFF0000u), s.y);
+    s.z = fmaf(cf, __uint_as_float(e.y << 16), s.z);
+    s.w = fmaf(cf, __uint_as_float(e.y & 0xFFFF0000u), s.w);
+  }
   *reinterpret_cast<float4*>(dst + row * D + c * 4) = s;
 }
 
@@ -1126,16 +1133,21 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
 }
 
 int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse, const float* coef,
-                        const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t s) {
-  CQL_REQUIRE(ws && lse && coef && act && E_out_b && dH, "qhead_dh_finish: NULL pointer");
+                        const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t s, int part) {
+  CQL_REQUIRE(ws && lse && act && E_out_b && dH && (coef || part == 1) && part >= 0 && part <= 2, "qhead_dh_finish: bad arguments");
   const FusedWs f = fused_ws(const_cast<void*>(ws), rows, n_items, d);
   CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
   const int64_t n4 = rows * (d / 4);
   dim3 grid(cql_ceil_div(n4, 256)), block(256);
-#define FIN_DH(DD)                                                                                                   \
-  hipLaunchKernelGGL(qhead_dh_finish_kernel<DD>, grid, block, 0, s, f.slab, f.part_a, f.sp.nsplit, rows, lse, scale, \
+#define FIN_DH(DD, PP)                                                                                                   \
+  hipLaunchKernelGGL((qhead_dh_finish_kernel<DD, PP>), grid, block, 0, s, f.slab, f.part_a, f.sp.nsplit, rows, lse, scale, \
                      coef, act, E_out_b, dH)
-  if (d == 64) FIN_DH(64); else if (d == 128) FIN_DH(128); else FIN_DH(256);
+#define FIN_DH_D(PP)                                                                                                     \
+  do {                                                                                                                   \
+    if (d == 64) FIN_DH(64, PP); else if (d == 128) FIN_DH(128, PP); else FIN_DH(256, PP);                               \
+  } while (0)
+  if (part == 0) FIN_DH_D(0); else if (part == 1) FIN_DH_D(1); else FIN_DH_D(2);
+#undef FIN_DH_D
 #undef FIN_DH
   CQL_LAUNCH_CHECK("qhead_dh_finish");
   return CQLREC_OK;

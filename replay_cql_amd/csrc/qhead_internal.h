@@ -77,7 +77,8 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
                          int flag_cleared = 0);               // cql_qhead_fwd_lse_dh_prepare ran on this stream already
 int cql_qhead_fwd_lse_dh_prepare(void* ws, int64_t rows, int64_t n_items, int32_t d, hipStream_t s);
 int cql_qhead_dh_finish(const void* ws, int64_t rows, int64_t n_items, int32_t d, const float* lse, const float* coef,
-                        const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t stream);
+                        const int32_t* act, const uint16_t* E_out_b, float scale, float* dH, hipStream_t stream,
+                        int part = 0);     // 0: all of dH; 1: the soft part (coef may be NULL); 2: + coef * E_out_b[a] (1 then 2 = 0, bit for bit)
 // do_sparse: issue the scatter in this call; [item_lo, item_hi): item rows the streaming kernel handles in this call.
 int cql_qhead_bwd_items_acc(const uint16_t* H_b, const float* nlse2, const float* coef, const int32_t* act, int64_t batch,
                             const uint16_t* E_out_b, const float* b_out, int64_t n_items, int32_t d, float scale, void* ws,

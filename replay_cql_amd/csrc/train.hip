@@ -255,6 +255,10 @@ int sample_ahead(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream,
 }
 
 int backward_items_long_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream, CqlAdamFix* fix);
+static bool dh_early() {
+  static const bool v = !(getenv("CQL_DH_EARLY") && getenv("CQL_DH_EARLY")[0] == '0');
+  return v;
+}
 // early_items (a stream) + early_fix: the long item-side kernel of THIS step is launched on that stream as soon as the fused
 // forward has produced -lse (it needs nothing from the loss), see backward_items_impl
 int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlrec_stream stream, hipEvent_t eout_ready,
@@ -329,6 +333,9 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
     CQL_HIP_TRY(hipStreamWaitEvent(early_items, ss.fwd_done, 0), "train_step_forward");
     CQL_TRY(backward_items_long_impl(c, step, (cqlrec_stream)early_items, early_fix));
   }
+  // the part of dH that needs nothing from the loss, off the chain the next prologue waits for (CQL_DH_EARLY=0: A/B)
+  if (dh_early())
+    CQL_TRY(cql_qhead_dh_finish(w.ws_qb, B, N, d, w.lse, nullptr, w.act, p.Eout_b, alpha_scale(c), w.dH, s, 1));
   CQL_TRY(cqlrec_gather_dot(w.hb, p.Eout_b, p.b_out, w.act, B, d, w.q_a, stream));
   // ---- branch B
   if (!corun) CQL_TRY(branch_b_prologue());
@@ -408,8 +415,9 @@ int backward_states_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream
   StepWs w = carve_step(c->ws, B, N, d, c->window, step);
   const StepPtrs p = step_ptrs(c);
   // the catalogue pass was done by the forward: only the slabs are combined here (scale, exp(m - lse), + coef * E[a])
+  // (the soft part was formed by the forward, right behind the catalogue pass: here only the term that needs the loss)
   CQL_TRY(cql_qhead_dh_finish(w.ws_qb, B, N, d, w.lse, w.coef, w.act, p.Eout_b, alpha_scale(c), w.dH,
-                              (hipStream_t)stream));
+                              (hipStream_t)stream, dh_early() ? 2 : 0));
   SideStream& ss = side_stream();
   if (ss.ok) CQL_HIP_TRY(hipEventRecord(ss.dh, (hipStream_t)stream), "train_step_backward_rest");
   return CQLREC_OK;
