@@ -28,6 +28,61 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+
+def _self_launch_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the
+    launcher.  It starts N fresh children of this same script -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1 -- BEFORE torch is imported, so the parent never touches the
+    GPU (no exec from a process that has initialised HIP).  Rank 0 inherits stdout and prints the ONE JSON line; the
+    parent exits with the worst child return code, and stops the remaining ranks (by their exact PIDs) as soon as one
+    has failed, so a crashed rank cannot leave the others waiting in a collective."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n, argv = 1, sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                print(f"[bench] rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in sorted(live):
+                    procs[o].terminate()
+        time.sleep(0.05)
+    for pr in procs:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:      # a rank that ignores SIGTERM (stuck in a collective)
+            pr.kill()
+    sys.exit(worst)
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()
+
 import torch  # noqa: E402
 
 CONFIGS = {
@@ -163,9 +218,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:      # (a bare `--gpus N` was turned into N ranks by _self_launch_if_needed above)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     # rehearsal knobs (not used by the driver): several ranks on ONE GPU with gloo, to exercise the N > 1 code path
     backend = os.environ.get("CQL_DIST_BACKEND", "nccl")
     if os.environ.get("CQL_BENCH_SINGLE_DEVICE"):
@@ -176,10 +230,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a bounded timeout: a rank that fails on its own (before a collective its peers already sit in) makes the job
+        # FAIL after this long instead of hanging it
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("CQL_DIST_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)      # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
         pg = dist.group.WORLD
 
     from replay_cql_amd import _native as N

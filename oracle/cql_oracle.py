@@ -241,6 +241,28 @@ def argmax_rows(Q):
     return Q.argmax(axis=1).astype(np.int32)
 
 
+def argmax_margin_violations(a_got, a_ref, q_max_ref, hb_ref, E_out_b, b_out, hb_got=None, tol=1e-4):
+    """P3 for the double-Q arg-max, per row (not as a rate): rows b with a_got[b] != a_ref[b] that are NOT excused.
+
+    A differing row is excused only if the item chosen is a near-tie: Q_ref[b, a_got[b]] >= max_j Q_ref[b, j] - tol.
+    Where the checked path's own bf16 state vector differs from the oracle's (hb_got given: a one-ulp flip of a bf16
+    rounding upstream of the Q-head), the row is judged on the scores of THAT vector instead -- its choice must be a
+    near-tie of its own row maximum -- so no row can be wrong by more than tol under either reading.
+    Returns the array of violating row indices (empty = pass)."""
+    a_got, a_ref = np.asarray(a_got, dtype=np.int64), np.asarray(a_ref, dtype=np.int64)
+    bad = []
+    for b in np.nonzero(a_got != a_ref)[0]:
+        q_sel = np.float32(hb_ref[b] @ E_out_b[a_got[b]] + b_out[a_got[b]])
+        if q_sel >= q_max_ref[b] - np.float32(tol):
+            continue
+        if hb_got is not None and not np.array_equal(hb_got[b], hb_ref[b]):
+            row = (E_out_b @ hb_got[b] + b_out).astype(np.float32)
+            if row[a_got[b]] >= row.max() - np.float32(tol):
+                continue
+        bad.append(int(b))
+    return np.asarray(bad, dtype=np.int64)
+
+
 # --------------------------------------------------------------------------------------
 # S5 + backward: one training step's gradients
 # --------------------------------------------------------------------------------------
@@ -258,6 +280,7 @@ class StepOut:
     hb_sn: np.ndarray
     dH: np.ndarray
     dh0: np.ndarray
+    qn_max: Optional[np.ndarray] = None   # max_j Q_theta(s', j): what an arg-max that differs from a_star is judged by
 
 
 def shadow(flat: np.ndarray) -> np.ndarray:
@@ -317,6 +340,7 @@ def loss_and_grads(
     q_a = Q_s[np.arange(B), act]
     Q_n = qvalues(hb_sn, E_out_b, b_out)
     a_star = argmax_rows(Q_n)
+    qn_max = Q_n.max(axis=1).astype(np.float32)
     del Q_n
     q_targ = (np.einsum("bd,bd->b", hb_tn, Et_b[a_star], dtype=np.float32) + bt[a_star]).astype(np.float32)
     y = (rew + np.float32(gamma) * (np.float32(1) - done) * q_targ).astype(np.float32)
@@ -357,7 +381,7 @@ def loss_and_grads(
         m = len_s >= j
         np.add.at(g_Ein, items[base[m] - len_s[m] + (j - 1)], contrib[m])
 
-    return StepOut(loss, grads, q_a, lse, a_star, q_targ, y, h0_s, hb_s, hb_sn, dH, dh0)
+    return StepOut(loss, grads, q_a, lse, a_star, q_targ, y, h0_s, hb_s, hb_sn, dH, dh0, qn_max)
 
 
 # --------------------------------------------------------------------------------------

@@ -130,10 +130,14 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
   __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)a.E_b, 0, (int)(a.n_cand * C::ROWB), 0x00020000);
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (int)(a.n_cand * 4), 0x00020000);
   // seen words of this wave's 64 users: [stage][64 users][2 words], 512 B per stage; no filter = an empty buffer (reads 0)
+  // A wave whose 64 users all lie past n_users (the tail of the last 256-user row-block) has no group in the bitmap --
+  // it holds ceil(n_users / 64) groups -- and gets the empty buffer too: its rows are discarded, and num_records is
+  // relative to wsrc, so the hardware bounds check would not stop the reads behind the bitmap's end.
   const int64_t nst_all = (a.n_cand + C::TI - 1) / C::TI;
-  const uint32_t* wsrc = a.seen_bits ? a.seen_bits + (res0 >> 6) * nst_all * 128 : (const uint32_t*)a.bias;
+  const bool has_seen = a.seen_bits != nullptr && res0 < a.n_users;        // wave-uniform
+  const uint32_t* wsrc = has_seen ? a.seen_bits + (res0 >> 6) * nst_all * 128 : (const uint32_t*)a.bias;
   __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, a.seen_bits ? (int)(nst_all * 512) : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, 0, has_seen ? (int)(nst_all * 512) : 0, 0x00020000);
   uint32_t voff;
   {
     const int sub = lane >> 5, r7 = (lane >> 2) & 7, slot = lane & 3;

@@ -4,6 +4,7 @@
 // outputs and scratch through torch's caching allocator, and calls the C ABI of include/cqlrec.h on the CURRENT HIP
 // stream.  No arithmetic lives here; the kernels are in libcqlrec.so, which this library links against.
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -19,8 +20,21 @@ cqlrec_stream cur_stream(const Tensor& t) {
   return (cqlrec_stream)c10::hip::getCurrentHIPStream(t.device().index()).stream();
 }
 void ok(int rc, const char* what) { TORCH_CHECK(rc == CQLREC_OK, "cqlrec.", what, ": ", cqlrec_last_error()); }
+// Every op opens with `OpDevice dev_(first tensor)`: the op's device becomes the CURRENT device for its duration (the
+// library's per-device tables -- side streams, LDS opt-ins -- are indexed by hipGetDevice(), and a launch must go to
+// the device whose stream it is given), and every further tensor argument must live on that same device.
+thread_local c10::Device g_op_device(c10::DeviceType::CPU);
+struct OpDevice {
+  c10::hip::HIPGuard guard;
+  explicit OpDevice(const Tensor& first) : guard(first.device()) {
+    TORCH_CHECK(first.is_cuda(), "cqlrec ops take GPU tensors");
+    g_op_device = first.device();
+  }
+};
 void dev_contig(const Tensor& t, at::ScalarType st, const char* name) {
   TORCH_CHECK(t.is_cuda(), name, " must live on the GPU");
+  TORCH_CHECK(t.device() == g_op_device, name, " is on ", t.device(), " but the op's first tensor is on ", g_op_device,
+              ": all tensor arguments must share one device");
   TORCH_CHECK(t.scalar_type() == st, name, " must be ", c10::toString(st), ", got ", c10::toString(t.scalar_type()));
   TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
 }
@@ -33,9 +47,14 @@ Tensor scratch(int64_t bytes, const Tensor& like) {
 }
 
 // h0 (fp32) and h0_b (bf16) of n states: state i = last min(end_i, L) items of users[i] before ends[i] + end_delta
+// ID-RANGE CONTRACT (gather_pool_fwd / gather_pool_bwd): items in [0, E_in_b.size(0) - 1) resp. [0, n_items), users in
+// [0, offsets.numel() - 1), ends within the user's row -- the kernels index E_in / g_E_in with them unguarded, and
+// checking here would cost a device->host sync per call.  Validate a log ONCE where it enters (CQLCore.set_log and
+// CQL._device_states do: one min/max reduction), not per op.
 std::tuple<Tensor, Tensor> gather_pool_fwd(const Tensor& E_in_b, const Tensor& offsets, const Tensor& items,
                                            const Tensor& users, const optional<Tensor>& ends, int64_t end_delta,
                                            int64_t window) {
+  OpDevice dev_(E_in_b);
   dev_contig(E_in_b, at::kBFloat16, "E_in_b");
   dev_contig(offsets, at::kLong, "offsets");
   dev_contig(items, at::kInt, "items");
@@ -56,6 +75,7 @@ std::tuple<Tensor, Tensor> gather_pool_fwd(const Tensor& E_in_b, const Tensor& o
 // g_E_in [n_rows x d] (zero-initialised here) += dh0[i] / len_i over the window rows; deterministic sorted form
 Tensor gather_pool_bwd(const Tensor& dh0, const Tensor& offsets, const Tensor& items, const Tensor& users,
                        const optional<Tensor>& ends, int64_t end_delta, int64_t window, int64_t n_items) {
+  OpDevice dev_(dh0);
   dev_contig(dh0, at::kFloat, "dh0");
   dev_contig(offsets, at::kLong, "offsets");
   dev_contig(items, at::kInt, "items");
@@ -78,6 +98,7 @@ Tensor gather_pool_bwd(const Tensor& dh0, const Tensor& offsets, const Tensor& i
 
 // (lse, -lse*log2e) of Q = H_b E_out_b^T + b_out per row; the score matrix never reaches HBM
 std::tuple<Tensor, Tensor> qhead_lse_fwd(const Tensor& H_b, const Tensor& E_out_b, const Tensor& b_out) {
+  OpDevice dev_(H_b);
   dev_contig(H_b, at::kBFloat16, "H_b");
   dev_contig(E_out_b, at::kBFloat16, "E_out_b");
   dev_contig(b_out, at::kFloat, "b_out");
@@ -95,6 +116,7 @@ std::tuple<Tensor, Tensor> qhead_lse_fwd(const Tensor& H_b, const Tensor& E_out_
 
 // (max_j Q, argmax_j Q (ties -> smallest j)) per row
 std::tuple<Tensor, Tensor> qhead_argmax_fwd(const Tensor& H_b, const Tensor& E_out_b, const Tensor& b_out) {
+  OpDevice dev_(H_b);
   dev_contig(H_b, at::kBFloat16, "H_b");
   dev_contig(E_out_b, at::kBFloat16, "E_out_b");
   dev_contig(b_out, at::kFloat, "b_out");
@@ -114,6 +136,7 @@ std::tuple<Tensor, Tensor> qhead_argmax_fwd(const Tensor& H_b, const Tensor& E_o
 std::tuple<Tensor, Tensor, Tensor> qhead_lse_bwd(const Tensor& H_b, const Tensor& nlse2, const Tensor& coef,
                                                  const Tensor& act, const Tensor& E_out_b, const Tensor& b_out,
                                                  double scale) {
+  OpDevice dev_(H_b);
   dev_contig(H_b, at::kBFloat16, "H_b");
   dev_contig(nlse2, at::kFloat, "nlse2");
   dev_contig(coef, at::kFloat, "coef");
@@ -135,6 +158,7 @@ std::tuple<Tensor, Tensor, Tensor> qhead_lse_bwd(const Tensor& H_b, const Tensor
 
 // out[r] = <H_b[r], E_b[idx[r]]> + b[idx[r]]
 Tensor qhead_gather_dot(const Tensor& H_b, const Tensor& E_b, const Tensor& b, const Tensor& idx) {
+  OpDevice dev_(H_b);
   dev_contig(H_b, at::kBFloat16, "H_b");
   dev_contig(E_b, at::kBFloat16, "E_b");
   dev_contig(b, at::kFloat, "b");
@@ -152,6 +176,7 @@ Tensor qhead_gather_dot(const Tensor& H_b, const Tensor& E_b, const Tensor& b, c
 std::tuple<Tensor, Tensor, Tensor> score_topk(const Tensor& H_b, const Tensor& E_b, const Tensor& b, int64_t k,
                                               const optional<Tensor>& item_ids, const optional<Tensor>& seen_off,
                                               const optional<Tensor>& seen_items, const optional<Tensor>& seen_rows) {
+  OpDevice dev_(H_b);
   dev_contig(H_b, at::kBFloat16, "H_b");
   dev_contig(E_b, at::kBFloat16, "E_b");
   dev_contig(b, at::kFloat, "b");
@@ -180,6 +205,7 @@ std::tuple<Tensor, Tensor, Tensor> score_topk(const Tensor& H_b, const Tensor& E
 void fused_adam_ema(Tensor theta, Tensor grads, Tensor m, Tensor v, Tensor target, Tensor theta_b, Tensor target_b,
                     double step_size, double sqrt_bc2, double beta1, double beta2, double eps, double tau,
                     bool zero_grads) {
+  OpDevice dev_(theta);
   for (const Tensor* t : {&theta, &grads, &m, &v, &target}) dev_contig(*t, at::kFloat, "theta/grads/m/v/target");
   dev_contig(theta_b, at::kBFloat16, "theta_b");
   dev_contig(target_b, at::kBFloat16, "target_b");

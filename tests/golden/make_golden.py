@@ -43,12 +43,22 @@ def make(name):
     losses = O.train_steps(m, off, items, rew, steps, B, L, seed=11)
     idx, val, cnt, _ = O.predict_topk(m.layout, m.theta, off, items, np.arange(U), k, L, filter_seen=True)
     lay = m.layout
+    # Trained parameters, as what the scoring pass depends on (so that the top-K after training can be checked to the
+    # 1e-3 / 1e-4 rules on the FIXTURE's parameters instead of on parameters the checked path trained itself, which
+    # agree to 1e-3 only): the bf16 shadow as a signed difference of bit patterns against the initial shadow (a few
+    # ulps after `steps` Adam steps: compresses to a fraction of a byte per parameter) + the fp32 biases in full.
+    th0 = O.init_params(lay, 7, dyadic)
+    b_delta = (O.bf16_bits(m.theta).astype(np.int32) - O.bf16_bits(th0).astype(np.int32)).astype(np.int16)
+    assert np.array_equal((O.bf16_bits(th0).astype(np.int32) + b_delta).astype(np.uint16), O.bf16_bits(m.theta))
     np.savez_compressed(
         OUT / f"{name}.npz",
         case=np.array([U, Nn, d, L, B, steps, int(dyadic), ls]),
         log_user=u.astype(np.int32), log_item=i.astype(np.int32), log_ts=t.astype(np.int32), log_rel=r.astype(np.float32),
         theta0_probe=theta0_probe, topk0_idx=idx0, topk0_val=val0, topk0_cnt=cnt0,
         users=users, tpos=tpos, q_a=out.q_a, lse=out.lse, a_star=out.a_star, q_targ=out.q_targ, y=out.y,
+        qn_max=out.qn_max, hb_sn_bits=O.bf16_bits(out.hb_sn),
+        trained_shadow_delta=b_delta, trained_b_out=lay.view(m.theta, "b_out").copy(),
+        trained_b1=lay.view(m.theta, "b1").copy(), trained_b2=lay.view(m.theta, "b2").copy(),
         loss0=np.float64(out.loss), grad_norms=np.array([np.linalg.norm(lay.view(out.grads, n)) for n in
                                                          ("E_in", "E_out", "b_out", "W1", "b1", "W2", "b2")]),
         losses=np.array(losses), theta_sum=np.float64(m.theta.astype(np.float64).sum()),

@@ -78,7 +78,33 @@ def qhead_inputs(rows, Nn, d, dyadic, seed):
     return O.bf16_round(H), O.bf16_round(E), b
 
 
-def topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None):
+def topk_rule_violations(idx, val, cnt, Q, k, set_tol=1e-4, val_tol=1e-3):
+    """P3 for a block of top-k lists against the reference score matrix Q (rows = the same users, inadmissible items at
+    -inf), PER ROW: the count of admissible items, descending order, every reported score within val_tol of the
+    reference's score of that item, and the set equal to the reference's outside a set_tol margin around the k-th
+    reference score (an item in one list only must score within set_tol of it).  Returns (rows that violate it,
+    number of boundary swaps over the passing rows)."""
+    bad, swaps = [], 0
+    ar = np.arange(Q.shape[1])
+    for u in range(Q.shape[0]):
+        order = np.lexsort((ar, -Q[u].astype(np.float64)))[:k]
+        rv = Q[u][order]
+        c = int(np.isfinite(rv).sum())
+        ok = int(cnt[u]) == c and np.all(np.diff(val[u, :c]) <= 0)
+        if ok and c:
+            got = idx[u, :c].astype(np.int64)
+            ok = (np.unique(got).size == c and got.min() >= 0 and
+                  np.all(np.abs(val[u, :c] - Q[u, got]) <= val_tol))
+            if ok:
+                diff = set(got.tolist()) ^ set(order[:c].tolist())
+                ok = all(abs(float(Q[u, j]) - float(rv[c - 1])) < set_tol for j in diff)
+                swaps += len(diff) // 2
+        if not ok:
+            bad.append(u)
+    return np.asarray(bad, dtype=np.int64), swaps
+
+
+def topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None, guard_bytes=0):
     Hb, Eb, b = qhead_inputs(n_users, Nn, d, dyadic, seed)
     rng = np.random.default_rng(seed)
     ids = np.arange(Nn, dtype=np.int32) if cand is None else cand
@@ -108,7 +134,9 @@ def topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None):
     idx_ref = np.where(np.isfinite(val_ref), ids[idx_c], -1)
 
     nb = int(lib.cqlrec_topk_ws_bytes(n_users, len(ids), d, k))
-    ws = ws_bytes_tensor(nb)
+    ws = ws_bytes_tensor(nb + guard_bytes)         # guard_bytes > 0: a poisoned region right behind the declared size
+    if guard_bytes:
+        ws[nb:] = 0xFF                             # "every item seen" if a live row ever read it as bitmap
     out_idx = torch.empty((n_users, k), dtype=torch.int32, device=DEV)
     out_val = torch.empty((n_users, k), dtype=torch.float32, device=DEV)
     out_cnt = torch.empty(n_users, dtype=torch.int32, device=DEV)
@@ -119,4 +147,6 @@ def topk_case(lib, n_users, Nn, d, k, dyadic, seed, with_seen, cand=None):
                                   ptr(d_so), ptr(d_si), None, k, ptr(ws), nb, ptr(out_idx), ptr(out_val), ptr(out_cnt),
                                   stream()))
     sync()
+    if guard_bytes:
+        assert bool((ws[nb:] == 0xFF).all()), "the pass wrote behind the workspace size it asked for"
     return out_idx.cpu().numpy(), out_val.cpu().numpy(), out_cnt.cpu().numpy(), idx_ref, val_ref, Q

@@ -158,3 +158,25 @@ def test_fit_arrays_data_parallel_unequal_shards():
     assert np.array_equal(a[1], b[1])                             # replicas bit-identical
     assert np.array_equal(a[3], b[3]) and a[4] == b[4] and a[5] == b[5]
     assert np.allclose(a[2], b[2])                                # the reduced loss
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver's scaling run invokes it): the parent --
+    which never touches the GPU -- starts one child per rank, rank 0 prints the ONE JSON line, the exit code is the
+    children's worst.  Rehearsed with both ranks on this one GPU over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(CQL_DIST_BACKEND="gloo", CQL_BENCH_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "10",
+                        "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["config"]["dp_variant"] in ("sharded", "allreduce")
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]

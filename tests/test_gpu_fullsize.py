@@ -76,7 +76,11 @@ def test_published_shape_step_matches_oracle(name, users_total, Nn, d, B, L, sha
     np.testing.assert_allclose(v["lse"].cpu().numpy(), out.lse, atol=1e-3)
     np.testing.assert_allclose(v["q_targ"].cpu().numpy(), out.q_targ, atol=1e-3)
     np.testing.assert_allclose(v["y"].cpu().numpy(), out.y, atol=1e-3)
-    assert np.mean(v["a_star"].cpu().numpy() == out.a_star) > 0.98
+    # arg-max per row (P3): a row that differs from the oracle must have picked a near-tie (<= 1e-4 below the maximum)
+    bad = O.argmax_margin_violations(v["a_star"].cpu().numpy(), out.a_star, out.qn_max, out.hb_sn,
+                                     lay.view(O.shadow(m.theta), "E_out"), lay.view(m.theta, "b_out"),
+                                     hb_got=bf16_to_np(v["hb_sn"]))
+    assert bad.size == 0, bad
     assert abs(loss.item() - out.loss) < 1e-3 * abs(out.loss)
     # ---- backward: per segment, normwise
     assert rel_err(v["dH"].cpu().numpy(), out.dH) < 5e-3
@@ -194,13 +198,11 @@ def test_cfg5_shard_shape_properties():
         lse_ref[lo: lo + 256] = torch.logsumexp(Q.double(), 1).float()
         Qn = hb_sn[lo: lo + 256] @ E.T + b_out
         vmax_ref[lo: lo + 256], amax_ref[lo: lo + 256] = Qn.max(1)
-        if lo == 0:
-            got = v["a_star"][:256].to(torch.int64)
-            # the chosen item's score is within 1e-4 of the row maximum (P3 margin rule)
-            assert torch.all(Qn.gather(1, got[:, None])[:, 0] >= vmax_ref[:256] - 1e-4)
+        # every row: the chosen item's score is within 1e-4 of the row maximum (P3 margin rule, per row)
+        got = v["a_star"][lo: lo + 256].to(torch.int64)
+        assert torch.all(Qn.gather(1, got[:, None])[:, 0] >= vmax_ref[lo: lo + 256] - 1e-4)
     del Q, Qn
     torch.testing.assert_close(v["lse"], lse_ref, rtol=0, atol=1e-3)
-    assert (v["a_star"].to(torch.int64) == amax_ref).float().mean() > 0.98
     q_a_ref = (hb_s * E[act]).sum(1) + b_out[act]
     torch.testing.assert_close(v["q_a"], q_a_ref, rtol=0, atol=1e-3)
     # ---- gradient identities

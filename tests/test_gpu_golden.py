@@ -75,6 +75,7 @@ def _seen(off, items):
 def test_hip_step_reproduces_golden(name):
     z, (U, Nn, d, L, B, steps, dyadic), core, (off, items, rew), stride = _case(name)
     lay = core.layout
+    theta0 = core.theta.cpu().numpy()
     loss = torch.zeros(1, device=DEV)
     core.forward_backward(loss)
     v = {k: t.cpu().numpy() for k, t in core.views().items() if t.dtype != torch.bfloat16}
@@ -86,7 +87,7 @@ def test_hip_step_reproduces_golden(name):
     else:
         np.testing.assert_allclose(v["q_a"], z["q_a"], atol=1e-3)                                # P3
         np.testing.assert_allclose(v["q_targ"], z["q_targ"], atol=1e-3)
-        assert np.mean(v["a_star"] == z["a_star"]) > 0.98
+        _argmax_rule(v["a_star"], z, theta0, lay, core.views()["hb_sn"])
     np.testing.assert_allclose(v["lse"], z["lse"], atol=1e-3)
     np.testing.assert_allclose(v["y"], z["y"], atol=1e-3)
     assert abs(loss.item() - float(z["loss0"])) < 1e-3 * abs(float(z["loss0"]))
@@ -117,17 +118,62 @@ def test_hip_topk_reproduces_golden(name):
         assert np.array_equal(idx, z["topk0_idx"]) and np.array_equal(val, z["topk0_val"])     # ids, order, scores
     else:
         _margin_rule(idx, val, cnt, z["topk0_idx"], z["topk0_val"], tol=1e-3, max_swaps=max(4, nu0 // 20))
-    # ---- after the fixture's training steps: the parameters agree to 1e-3 only, so does the ranking
-    core.train(steps)
+    # ---- after the fixture's training steps, on the FIXTURE's trained parameters (the scoring pass depends on the bf16
+    # shadows and the fp32 biases only; the fixture holds exactly those): scores within 1e-3, sets equal outside a 1e-4
+    # margin around the k-th score (P3) -- not on parameters this path trained itself, which agree to 1e-3 only
+    core.load_flat(_trained_theta(z, core.theta.cpu().numpy(), core.layout))
     users = torch.arange(U, dtype=torch.int32, device=DEV)
-    hb = core.encode(off, items, users)
-    idx, val, cnt = (t.cpu().numpy() for t in core.score_topk(hb, k, seen=seen, seen_rows=users))
+    idx, val, cnt = (t.cpu().numpy() for t in core.encode_topk(off, items, users, k, seen=seen))
+    assert np.array_equal(cnt, z["topk_cnt"])
+    _margin_rule(idx, val, cnt, z["topk_idx"], z["topk_val"], tol=1e-3, max_swaps=max(4, U // 50), set_tol=1e-4)
+    # ---- and the ranking of the parameters this path trains itself stays within the trajectory's 1e-3 (P4)
+    core.load_flat(_init_theta(core.layout, dyadic))
+    core.train(steps)
+    idx, val, cnt = (t.cpu().numpy() for t in core.encode_topk(off, items, users, k, seen=seen))
     assert np.array_equal(cnt, z["topk_cnt"])
     _margin_rule(idx, val, cnt, z["topk_idx"], z["topk_val"], tol=5e-3, max_swaps=max(4, U // 10))
 
 
-def _margin_rule(idx, val, cnt, ridx, rval, tol, max_swaps):
-    """P3 without the score matrix: items in one list only must sit within `tol` of the other list's k-th score."""
+def _bf16_bits(x):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def _bf16_vals(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def _trained_theta(z, theta0, lay):
+    """The fixture's trained parameters as a flat fp32 buffer whose bf16 shadow and biases are the oracle's."""
+    bits = (_bf16_bits(theta0).astype(np.int32) + z["trained_shadow_delta"].astype(np.int32)).astype(np.uint16)
+    flat = _bf16_vals(bits).copy()
+    for nm in ("b_out", "b1", "b2"):
+        o = lay.offset(nm)
+        flat[o: o + z["trained_" + nm].size] = z["trained_" + nm]
+    return flat
+
+
+def _argmax_rule(a_got, z, theta0, lay, hb_got_t):
+    """P3 for the double-Q arg-max, PER ROW: a row that differs from the fixture must have picked a near-tie -- its score
+    at most 1e-4 below the row maximum, on the fixture's state vector, or (where this path's own bf16 state vector is a
+    one-ulp flip away from the fixture's) on its own."""
+    n, d = int(lay.n_items), int(lay.d)
+    o = lay.offset("E_out")
+    E_b = _bf16_vals(_bf16_bits(theta0[o: o + n * d])).reshape(n, d)
+    b_out = theta0[lay.offset("b_out"): lay.offset("b_out") + n]
+    hb_ref = _bf16_vals(z["hb_sn_bits"])
+    hb_got = hb_got_t.float().cpu().numpy()
+    for b in np.nonzero(a_got != z["a_star"])[0]:
+        if np.float32(hb_ref[b] @ E_b[a_got[b]] + b_out[a_got[b]]) >= z["qn_max"][b] - np.float32(1e-4):
+            continue
+        assert not np.array_equal(hb_got[b], hb_ref[b]), (b, a_got[b], z["a_star"][b])
+        row = (E_b @ hb_got[b] + b_out).astype(np.float32)
+        assert row[a_got[b]] >= row.max() - np.float32(1e-4), (b, a_got[b], z["a_star"][b])
+
+
+def _margin_rule(idx, val, cnt, ridx, rval, tol, max_swaps, set_tol=None):
+    """P3 without the score matrix: common items score within `tol`; items in one list only must sit within `set_tol`
+    (default: tol) of the other list's k-th score."""
+    set_tol = tol if set_tol is None else set_tol
     swaps = 0
     for u in range(idx.shape[0]):
         c = int(cnt[u])
@@ -136,10 +182,10 @@ def _margin_rule(idx, val, cnt, ridx, rval, tol, max_swaps):
             continue
         kth_ref, kth_got = rval[u, c - 1], val[u, c - 1]
         for j in got.keys() - ref.keys():
-            assert abs(got[j] - kth_ref) < tol, (u, j)
+            assert abs(got[j] - kth_ref) < set_tol, (u, j)
             swaps += 1
         for j in ref.keys() - got.keys():
-            assert abs(ref[j] - kth_got) < tol, (u, j)
+            assert abs(ref[j] - kth_got) < set_tol, (u, j)
         for j in got.keys() & ref.keys():
             assert abs(got[j] - ref[j]) < tol, (u, j)
         assert np.all(np.diff(val[u, :c]) <= 0)

@@ -51,7 +51,10 @@ def test_step_intermediates_and_grads(U, Nn, d, B, L):
     np.testing.assert_allclose(v["lse"].cpu().numpy(), out.lse, atol=1e-3)
     np.testing.assert_allclose(v["q_targ"].cpu().numpy(), out.q_targ, atol=1e-3)
     np.testing.assert_allclose(v["y"].cpu().numpy(), out.y, atol=1e-3)
-    assert np.mean(v["a_star"].cpu().numpy() == out.a_star) > 0.98
+    bad = O.argmax_margin_violations(v["a_star"].cpu().numpy(), out.a_star, out.qn_max, out.hb_sn,
+                                     lay.view(O.shadow(m.theta), "E_out"), lay.view(m.theta, "b_out"),
+                                     hb_got=bf16_to_np(v["hb_sn"]))
+    assert bad.size == 0, bad                                                    # per row, P3 margin rule
     assert abs(loss.item() - out.loss) < 1e-3 * abs(out.loss)
     assert rel_err(v["dH"].cpu().numpy(), out.dH) < 5e-3
     assert rel_err(v["dh0"].cpu().numpy(), out.dh0) < 5e-3

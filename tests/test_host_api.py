@@ -1,6 +1,8 @@
 """CPU tests of the host layer: the pandas mirror of the reference's Recommender wrappers (semantics cited from
 replay/models/base_rec.py), CSR construction, seen lists, the synthetic generator.  A deterministic fake model stands
 in for the GPU core so that the wrapper logic is tested without a GPU."""
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -218,3 +220,20 @@ def test_bench_hbm_roofline_never_reports_more_than_the_peak():
     assert big["frac"] == 1.0 and not big["infinity_cache_resident"]
     adam = bench.hbm_roofline(alg_bytes=11.8e9, ms=2.43, table_bytes=5.4e9)
     assert 0.55 < adam["frac"] < 0.65
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the failure path: needs a box WITHOUT a GPU")
+def test_bench_self_launch_propagates_a_failing_rank():
+    """bench.py --gpus 2 without a launcher starts its own ranks (tests/test_gpu_dp.py runs the real thing); here, with
+    no GPU, every rank fails at once: the parent must return a non-zero code promptly instead of hanging or printing a
+    JSON line."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "2",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "stopping the other ranks" in r.stderr or "exited with" in r.stderr
