@@ -248,7 +248,13 @@ def main():
     U, NI, d, L, B, K = cfg["users"], cfg["items"], cfg["d"], cfg["window"], cfg["batch"], cfg["k"]
     lo, hi = rank * U // world, (rank + 1) * U // world
     gen_kw = {k_: cfg[k_] for k_ in ("mean_len", "sigma", "max_len") if k_ in cfg}
-    off, items, rew = synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi, **gen_kw)
+
+    def gen_log():
+        return synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi, **gen_kw)
+    # Order of the set-up (nothing of it is timed): the model FIRST -- its parameters are drawn on the host and uploaded,
+    # seconds during which the GPU idles -- and the log LAST, generated on the device right in front of the warm-up
+    # steps, so that the warm-up starts on a GPU that has just been working instead of one that has clocked down
+    # (tools/step_ramp.py: from idle the first ~30 steps run 3-15 % slower, whatever their number).
     # Ranks > 1, two exchange patterns with the same bytes on the links: "sharded" = reduce-scatter of the
     # gradients, Adam on this rank's rows only, all-gather of the bf16 shadows (1/W of the Adam traffic per GPU);
     # "allreduce" = replicated Adam behind a gradient all-reduce.  The variant is chosen by --dp-variant and the run
@@ -259,16 +265,18 @@ def main():
         want = "allreduce" if world > 1 else want
     dp_probe = None
 
-    def make_core(shard):
+    def make_core(shard, log=None):
         c_ = CQLCore(NI, CQLHyper(d=d, window=L, batch=B, seed=0), device=dev, rank=rank, world=world, process_group=pg,
                      shard_optimizer=shard)
-        c_.set_log(off, items, rew)
+        if log is not None:
+            c_.set_log(*log)
         return c_
     if want == "auto":
+        off, items, rew = gen_log()
         import torch.distributed as dist
         failed, why = 0.0, ""
         try:
-            probe = make_core(True)
+            probe = make_core(True, (off, items, rew))
             probe.train_steps(1)
             torch.cuda.synchronize()
         except Exception as exc:  # pragma: no cover - needs a multi-GPU RCCL job
@@ -279,8 +287,11 @@ def main():
         want = "allreduce" if float(flag.item()) > 0 else "sharded"
         dp_probe = {"sharded_probe_failed_on_some_rank": bool(float(flag.item()) > 0), "rank0_error": why}
         probe = None                                        # the probe step is discarded: the timed run starts fresh
+        del off, items, rew
         torch.cuda.empty_cache()
     core = make_core(want == "sharded")
+    off, items, rew = gen_log()
+    core.set_log(off, items, rew)
 
     def barrier():
         if world > 1:

@@ -25,6 +25,9 @@
 #include "qhead_de_common.h"
 
 #define QDE2_ITEMS 256      // items per group: 4 waves x 2 x 32
+#ifndef QDE2_NBUF
+#define QDE2_NBUF 3         // ring depth (stages of 64 states): with 2 the pieces a turn waits for were issued ONE stage
+#endif                      // earlier and the wave parks on vmcnt(0) (PMC r02: 23 % of the wave's life in s_waitcnt / barrier)
 #ifndef QDE2_VALU_PER_MFMA
 #define QDE2_VALU_PER_MFMA 8   // VALU instructions the scheduler is asked to place behind each MFMA of slots 2 and 3
 #endif
@@ -82,18 +85,24 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
   // stage, so the stage body is written once and every LDS address in it is "base register + immediate"
   const lds_u8* lbase = (const lds_u8*)smem;
   const lds_u8 *pA0, *pA1, *pT0, *pT1, *pS;          // current buffer
-  const lds_u8 *nA0, *nA1, *nT0, *nT1, *nS;          // the other buffer
+  const lds_u8 *nA0, *nA1, *nT0, *nT1, *nS;          // the next buffer of the ring
+  int oa0, oa1, ot0, ot1, os;
   {
     const int g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-    const int oa0 = C::RG_BYTES * (r >> 3) + 64 * (r & 7) + 16 * ((0 + h) ^ ((r >> 2) & 3));
-    const int oa1 = C::RG_BYTES * (r >> 3) + 64 * (r & 7) + 16 * ((2 + h) ^ ((r >> 2) & 3));
-    const int ot0 = 64 * (4 * h + q) + 16 * ((2 * g1 + (p >> 1)) ^ ((0 + h) & 3)) + 8 * (p & 1);
-    const int ot1 = 64 * (4 * h + q) + 16 * ((2 * g1 + (p >> 1)) ^ ((2 + h) & 3)) + 8 * (p & 1);
-    const int os = C::STAGE_BYTES + 16 * h;
-    pA0 = lbase + oa0; pA1 = lbase + oa1; pT0 = lbase + ot0; pT1 = lbase + ot1; pS = lbase + os;
-    nA0 = pA0 + C::BUF_BYTES; nA1 = pA1 + C::BUF_BYTES; nT0 = pT0 + C::BUF_BYTES; nT1 = pT1 + C::BUF_BYTES;
-    nS = pS + C::BUF_BYTES;
+    oa0 = C::RG_BYTES * (r >> 3) + 64 * (r & 7) + 16 * ((0 + h) ^ ((r >> 2) & 3));
+    oa1 = C::RG_BYTES * (r >> 3) + 64 * (r & 7) + 16 * ((2 + h) ^ ((r >> 2) & 3));
+    ot0 = 64 * (4 * h + q) + 16 * ((2 * g1 + (p >> 1)) ^ ((0 + h) & 3)) + 8 * (p & 1);
+    ot1 = 64 * (4 * h + q) + 16 * ((2 * g1 + (p >> 1)) ^ ((2 + h) & 3)) + 8 * (p & 1);
+    os = C::STAGE_BYTES + 16 * h;
   }
+  // per-lane bases of buffers `bc` (current) and `bn` (next): recomputed when the ring turns (10 adds per 64 MFMAs)
+  auto set_ptrs = [&](int bc, int bn) {
+    const lds_u8* c0 = lbase + bc * C::BUF_BYTES;
+    const lds_u8* n0 = lbase + bn * C::BUF_BYTES;
+    pA0 = c0 + oa0; pA1 = c0 + oa1; pT0 = c0 + ot0; pT1 = c0 + ot1; pS = c0 + os;
+    nA0 = n0 + oa0; nA1 = n0 + oa1; nT0 = n0 + ot0; nT1 = n0 + ot1; nS = n0 + os;
+  };
+  set_ptrs(0, 1 % QDE2_NBUF);
 
   // ---- owner state: two 32-item groups per wave ----------------------------------------------------------------------
   bf16x8 rf[2][KS];
@@ -260,10 +269,20 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
   };
   // the ring turns (tile = last of its stage): the next stage's pieces have landed for everyone, everyone has left this
   // stage's buffer (its last reads were issued in the previous period), which is refilled with stage + 2
-  auto ring_turn = [&](bool more, bool refill, int cur_buf) {
+  // `younger` = stages issued behind the one the turn waits for (0 .. QDE2_NBUF - 2): their pieces -- LPS per stage, plus
+  // the strip of the stages whose strip THIS wave loads -- may stay in flight (vmcnt is counted in issue order)
+  auto ring_turn = [&](bool more, bool refill, int cur_buf, int younger) {
     if (more) {
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of the buffer refilled below (issued >= 4 gaps ago)
-      de_wait_vmcnt<0>();
+      int keep = 0;
+      if (QDE2_NBUF > 2 && a.T >= QDE2_NBUF) {      // (short batches: the conservative full wait)
+        int tq = t_dma;
+        for (int q = 0; q < younger; ++q) {
+          tq = (tq == 0) ? a.T - 1 : tq - 1;         // in-group index of the q-th youngest stage issued
+          keep += C::LPS + ((wave == (tq & 3)) ? 1 : 0);
+        }
+      }
+      de_wait_vmcnt_rt(keep);
 #ifndef QDE_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
 #endif
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
   // P fragments (they add nothing), at its last tile the A chain of the following tile is computed in vain (the next
   // piece redoes it with its own owner fragments) -- run-time variants of the period would duplicate the chains under a
   // branch, and hipcc then shuffles the accumulators at every join.
-  auto period = [&](auto IT, bool more, bool refill, int cur_buf) {
+  auto period = [&](auto IT, bool more, bool refill, int cur_buf, int younger) {
     constexpr int P = decltype(IT)::value & 1;                 // register set of this tile's transposed fragments
     constexpr bool END = decltype(IT)::value == C::TILES - 1;
     const int64_t left = MASK ? (a.n_states - ((int64_t)t * C::TI + 32 * decltype(IT)::value)) : 32;
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
       // ---- LDS reads of the next tile, one per gap: strip + rows in gaps 4-15 (second register set: B(t) and A(t+1)
       // run on different sets), transposed fragments in gaps 16-31.  The ring turns in front of the first of them.
       if (gp == 4) {
-        if constexpr (END) ring_turn(more, refill, cur_buf);
+        if constexpr (END) ring_turn(more, refill, cur_buf, younger);
       }
       if (gp >= 4) next_read(IT, gp - 4);
       QDE2_FENCE();
@@ -368,26 +387,18 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
 
   // ---- prologue: stages 0 and 1 in flight; rows, strip and transposed fragments of the first tile in registers ----
   int issued = 0;
-  for (int s0 = 0; s0 < 2 && s0 < nst; ++s0) {
+  for (int s0 = 0; s0 < QDE2_NBUF && s0 < nst; ++s0) {
     issue(t_dma, s0);
     ++issued;
     if (++t_dma == a.T) t_dma = 0;
   }
-  de_wait_vmcnt<0>();
+  de_wait_vmcnt<0>();        // (once per launch: the whole ring, not only stage 0)
   __builtin_amdgcn_s_barrier();
-  {   // "the tile following tile -1": read through next_read with the roles of the buffers swapped
-    { const lds_u8* x = pA0; pA0 = nA0; nA0 = x; }
-    { const lds_u8* x = pA1; pA1 = nA1; nA1 = x; }
-    { const lds_u8* x = pT0; pT0 = nT0; nT0 = x; }
-    { const lds_u8* x = pT1; pT1 = nT1; nT1 = x; }
-    { const lds_u8* x = pS; pS = nS; nS = x; }
+  {   // "the tile following tile -1": read through next_read with buffer 0 in the role of the NEXT buffer
+    set_ptrs(1 % QDE2_NBUF, 0);
 #pragma unroll
     for (int idx = 0; idx < 4 + KS + 4 * FT; ++idx) next_read(std::integral_constant<int, C::TILES - 1>{}, idx);
-    { const lds_u8* x = pA0; pA0 = nA0; nA0 = x; }
-    { const lds_u8* x = pA1; pA1 = nA1; nA1 = x; }
-    { const lds_u8* x = pT0; pT0 = nT0; nT0 = x; }
-    { const lds_u8* x = pT1; pT1 = nT1; nT1 = x; }
-    { const lds_u8* x = pS; pS = nS; nS = x; }
+    set_ptrs(0, 1 % QDE2_NBUF);
   }
 
   // pieces of item groups (outer) x stages of the piece (inner): the owner fragments are invariant in the inner loop
@@ -401,17 +412,14 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
     for (; j < seg_end; ++j) {
       const bool more = j + 1 < nst, refill = issued < nst;
       static_assert(C::TILES == 2, "two tiles per stage");
-      period(std::integral_constant<int, 0>{}, true, false, cur_buf);
-      period(std::integral_constant<int, 1>{}, more, refill, cur_buf);
+      const int younger = issued - (j + 2);        // stages in flight behind stage j + 1 when the ring turns
+      period(std::integral_constant<int, 0>{}, true, false, cur_buf, 0);
+      period(std::integral_constant<int, 1>{}, more, refill, cur_buf, younger > 0 ? younger : 0);
       if (more && refill) ++issued;
       ++t;
-      // the ring turned: the other buffer is the current one now
-      { const lds_u8* x = pA0; pA0 = nA0; nA0 = x; }
-      { const lds_u8* x = pA1; pA1 = nA1; nA1 = x; }
-      { const lds_u8* x = pT0; pT0 = nT0; nT0 = x; }
-      { const lds_u8* x = pT1; pT1 = nT1; nT1 = x; }
-      { const lds_u8* x = pS; pS = nS; nS = x; }
-      cur_buf ^= 1;
+      // the ring turned: the next buffer is the current one now
+      cur_buf = (cur_buf + 1 == QDE2_NBUF) ? 0 : cur_buf + 1;
+      set_ptrs(cur_buf, (cur_buf + 1 == QDE2_NBUF) ? 0 : cur_buf + 1);
     }
     drain_d(std::integral_constant<int, 1>{});
     store_piece(g, t_seg == 0);
@@ -437,7 +445,15 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
 // =============================================================================================================
 template <int D, bool MASK>
 static void qde2_launch_n(const QDeArgs& a, int grid, hipStream_t s) {
-  constexpr int smem = 2 * DeCfg<D, 4>::BUF_BYTES;
+  constexpr int smem = QDE2_NBUF * DeCfg<D, 4>::BUF_BYTES;
+  if constexpr (smem > 64 * 1024) {     // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
+    static bool attr_set_dev[CQL_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[cql_device_slot()];
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)qde2_kernel<D, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+  }
   hipLaunchKernelGGL((qde2_kernel<D, MASK>), dim3(grid), dim3(256), smem, s, a);
 }
 

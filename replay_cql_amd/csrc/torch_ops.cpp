@@ -4,7 +4,7 @@
 // outputs and scratch through torch's caching allocator, and calls the C ABI of include/cqlrec.h on the CURRENT HIP
 // stream.  No arithmetic lives here; the kernels are in libcqlrec.so, which this library links against.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -25,7 +25,7 @@ void ok(int rc, const char* what) { TORCH_CHECK(rc == CQLREC_OK, "cqlrec.", what
 // the device whose stream it is given), and every further tensor argument must live on that same device.
 thread_local c10::Device g_op_device(c10::DeviceType::CPU);
 struct OpDevice {
-  c10::hip::HIPGuard guard;
+  c10::DeviceGuard guard;      // (generic guard: on a ROCm build the "cuda" device type is served by the HIP implementation)
   explicit OpDevice(const Tensor& first) : guard(first.device()) {
     TORCH_CHECK(first.is_cuda(), "cqlrec ops take GPU tensors");
     g_op_device = first.device();
