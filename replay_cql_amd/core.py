@@ -78,6 +78,17 @@ class CQLCore:
         self.shard_optimizer = bool(shard_optimizer) and self.world > 1 and self.n_items >= self.world
         self._gshard: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
         self._tailpack: Optional[torch.Tensor] = None
+        self._agstage: Optional[Tuple[torch.Tensor, ...]] = None
+        # Replicated variant, how the gradient SUM travels: "allreduce" (one RCCL all-reduce per half) or "rsag" -- an
+        # explicit reduce-scatter into a persistent 1/W shard + all-gather back (each GPU exchanges S/W
+        # with each of its 7 xGMI peers per phase).  Same bytes, same sums in a different association order across
+        # ranks (every rank still ends with identical bits: each element is reduced on ONE rank).  Unmeasured on
+        # hardware (no multi-GPU box in this build); opt-in via CQL_DP_EXCHANGE=rsag.
+        import os as _os
+        self._exchange = _os.environ.get("CQL_DP_EXCHANGE", "allreduce")
+        if self._exchange not in ("allreduce", "rsag"):
+            raise ValueError("CQL_DP_EXCHANGE must be allreduce or rsag")
+        self._rsag_shards: Dict[Tuple[int, int], torch.Tensor] = {}
         self._topk_side: Optional[torch.cuda.Stream] = None
         self.init_params(init_seed)
 
@@ -267,15 +278,10 @@ class CQLCore:
 
     # ------------------------------------------------------------------ row-sharded optimizer (opt-in)
     def _shard_plan(self):
-        lay, d, W, r = self.layout, self.hyper.d, self.world, self.rank
-        R = self.n_items // W
-        n = R * d
-        o_in, o_out, o_w1, total = int(lay.off_E_in), int(lay.off_E_out), int(lay.off_W1), int(lay.total)
-        return {"n": n,
-                "in_region": (o_in, o_in + W * n), "in_own": (o_in + r * n, o_in + (r + 1) * n),
-                "out_region": (o_out, o_out + W * n), "out_own": (o_out + r * n, o_out + (r + 1) * n),
-                # replicated remainder: last N - W*R rows (+ PAD row and alignment padding), b_out, encoder
-                "tail_in": (o_in + W * n, o_out), "tail_out": (o_out + W * n, o_w1), "tail_enc": (o_w1, total)}
+        from .dist import shard_plan
+        lay = self.layout
+        return shard_plan(int(lay.off_E_in), int(lay.off_E_out), int(lay.off_W1), int(lay.total), self.n_items,
+                          self.hyper.d, self.world, self.rank)
 
     def _adam_shard(self, lo: int, hi: int, g: torch.Tensor, stream: int) -> None:
         """Adam + Polyak + shadows on elements [lo, hi) of the flat buffers with the gradient taken from `g` (the
@@ -309,6 +315,14 @@ class CQLCore:
             self._tailpack = torch.empty((P["tail_in"][1] - P["tail_in"][0]) + (P["tail_enc"][1] - P["tail_enc"][0]),
                                          dtype=torch.float32, device=self.device)
         pk = self._tailpack
+        if self._agstage is None:
+            # persistent send buffers of the four shadow all-gathers (theta_b / target_b x E_in / E_out rows): the step
+            # loop allocates nothing (a per-step clone would be held back by the collective's stream and churn the
+            # caching allocator: 2 x 2 x 64 MB per step at cfg5)
+            self._agstage = tuple(torch.empty(P["n"], dtype=torch.bfloat16, device=self.device) for _ in range(4))
+        st_in, st_out = self._agstage[:2], self._agstage[2:]
+        g_tail_in = self.grads[P["tail_in"][0]: P["tail_in"][1]]
+        g_tail_enc = self.grads[P["tail_enc"][0]: P["tail_enc"][1]]
         side = self._side
         ev_fwd, ev_rest, ev_items = self._ev
         pg = self.pg
@@ -345,19 +359,18 @@ class CQLCore:
             w_in = reduce_scatter_sum(g_in, self.grads[P["in_region"][0]: P["in_region"][1]], pg, async_op=True)
             # the two replicated remainders of the state side (last rows of E_in, encoder) travel as ONE all-reduce
             n1 = P["tail_in"][1] - P["tail_in"][0]
-            pk[:n1].copy_(self.grads[P["tail_in"][0]: P["tail_in"][1]])
-            pk[n1:].copy_(self.grads[P["tail_enc"][0]: P["tail_enc"][1]])
+            torch.cat([g_tail_in, g_tail_enc], out=pk)                  # packed by ONE kernel
             w_t = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=pg, async_op=True)
             wait(w_in), wait(w_t)
             self._adam_shard(P["in_own"][0], P["in_own"][1], g_in, s)
-            self.grads[P["tail_in"][0]: P["tail_in"][1]].copy_(pk[:n1])
-            self.grads[P["tail_enc"][0]: P["tail_enc"][1]].copy_(pk[n1:])
+            torch._foreach_copy_([g_tail_in, g_tail_enc], [pk[:n1], pk[n1:]])     # ... and unpacked by one
             upd(P["tail_in"][0], P["tail_in"][1], s)
             upd(P["tail_enc"][0], P["tail_enc"][1], s)
             self.grads[P["in_region"][0]: P["in_region"][1]].zero_()
-            w_ag = [all_gather_into(buf[P["in_region"][0]: P["in_region"][1]],
-                                    buf[P["in_own"][0]: P["in_own"][1]].clone(), pg, async_op=True)
-                    for buf in (self.theta_b, self.target_b)]
+            w_ag = []
+            for buf, stg in zip((self.theta_b, self.target_b), st_in):
+                stg.copy_(buf[P["in_own"][0]: P["in_own"][1]])
+                w_ag.append(all_gather_into(buf[P["in_region"][0]: P["in_region"][1]], stg, pg, async_op=True))
             with torch.cuda.stream(side):
                 w_out = reduce_scatter_sum(g_out, self.grads[P["out_region"][0]: P["out_region"][1]], pg, async_op=True)
                 w_t3 = ar(*P["tail_out"])
@@ -366,9 +379,9 @@ class CQLCore:
                 self._adam_shard(P["out_own"][0], P["out_own"][1], g_out, side.cuda_stream)
                 upd(P["tail_out"][0], P["tail_out"][1], side.cuda_stream)
                 self.grads[P["out_region"][0]: P["out_region"][1]].zero_()
-                for buf in (self.theta_b, self.target_b):
-                    wait(all_gather_into(buf[P["out_region"][0]: P["out_region"][1]],
-                                         buf[P["out_own"][0]: P["out_own"][1]].clone(), pg, async_op=True))
+                for buf, stg in zip((self.theta_b, self.target_b), st_out):
+                    stg.copy_(buf[P["out_own"][0]: P["out_own"][1]])
+                    wait(all_gather_into(buf[P["out_region"][0]: P["out_region"][1]], stg, pg, async_op=True))
                 ev_items.record(side)
             for w in w_ag:      # the next prologue (this stream) reads the gathered E_in shadows
                 wait(w)
@@ -386,12 +399,22 @@ class CQLCore:
         P = self._shard_plan()
         for buf in (self.theta, self.adam_m, self.adam_v, self.target):
             for reg, own in (("in_region", "in_own"), ("out_region", "out_own")):
-                all_gather_into(buf[P[reg][0]: P[reg][1]], buf[P[own][0]: P[own][1]].clone(), self.pg)
+                all_gather_into(buf[P[reg][0]: P[reg][1]], buf[P[own][0]: P[own][1]].clone(), self.pg)   # (not per step)
 
     def _allreduce_async(self, t: torch.Tensor):
+        """SUM over ranks of a contiguous piece of the flat gradient buffer, in place, asynchronous (returns the work to
+        wait on, or None)."""
         if self.world <= 1:
             return None
         import torch.distributed as dist
+        if self._exchange == "rsag" and t.numel() % self.world == 0 and t.numel() > 0:
+            from .dist import all_gather_into, reduce_scatter_sum
+            key = (t.data_ptr(), t.numel())
+            shard = self._rsag_shards.get(key)
+            if shard is None:           # persistent: one per region, created on first use
+                shard = self._rsag_shards[key] = torch.empty(t.numel() // self.world, dtype=t.dtype, device=t.device)
+            reduce_scatter_sum(shard, t, self.pg, async_op=True)       # same group: executes in issue order
+            return all_gather_into(t, shard, self.pg, async_op=True)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def train(self, n_steps: int, phased: Optional[bool] = None) -> torch.Tensor:

@@ -471,6 +471,19 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
     static unsigned long long host[1024];
     if (hipStreamSynchronize(s) == hipSuccess &&
         hipMemcpy(host, stamps_dev, (size_t)grid * 16, hipMemcpyDeviceToHost) == hipSuccess) {
+#ifdef QDE2_STAMP_TURN     // diagnostic build (tools/build_variant.sh x -DQDE2_STAMP_TURN): the second word is packed turn ticks
+      double tot = 0, lg = 0, vm = 0, bar = 0;
+      for (int i = 0; i < grid; ++i) {
+        tot += (double)host[2 * i];
+        lg += (double)((host[2 * i + 1] >> 40) & 0xFFFFF);
+        vm += (double)((host[2 * i + 1] >> 20) & 0xFFFFF);
+        bar += (double)(host[2 * i + 1] & 0xFFFFF);
+      }
+      fprintf(stderr, "[qde2 turn stamps] blocks=%d mean ticks/block %.0f; parked at ring turns (wave 0, raw, incl. ~2 stamp "
+              "latencies each): lgkmcnt %.1f %%  vmcnt %.1f %%  barrier %.1f %%\n", grid, tot / grid, 100 * lg / tot,
+              100 * vm / tot, 100 * bar / tot);
+      return CQLREC_OK;
+#endif
       double best_clk[512];
       double rt_max = 0;
       for (int i = 0; i < grid; ++i) {

@@ -271,20 +271,43 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
   // stage's buffer (its last reads were issued in the previous period), which is refilled with stage + 2
   // `younger` = stages issued behind the one the turn waits for (0 .. QDE2_NBUF - 2): their pieces -- LPS per stage, plus
   // the strip of the stages whose strip THIS wave loads -- may stay in flight (vmcnt is counted in issue order)
+#ifdef QDE2_STAMP_TURN      // diagnostic build: where a ring turn parks the wave (ticks of wave 0 per block, three intervals)
+  unsigned long long tt_lgkm = 0, tt_vm = 0, tt_bar = 0, tt_cal = 0;
+  {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    tt_cal = c1 - c0;            // what two stamps with nothing in between read
+  }
+#define QDE2_TSTAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define QDE2_TSTAMP(x)
+#endif
   auto ring_turn = [&](bool more, bool refill, int cur_buf, int younger) {
     if (more) {
+      QDE2_TSTAMP(ts0);
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's reads of the buffer refilled below (issued >= 4 gaps ago)
-      int keep = 0;
-      if (QDE2_NBUF > 2 && a.T >= QDE2_NBUF) {      // (short batches: the conservative full wait)
-        int tq = t_dma;
-        for (int q = 0; q < younger; ++q) {
-          tq = (tq == 0) ? a.T - 1 : tq - 1;         // in-group index of the q-th youngest stage issued
-          keep += C::LPS + ((wave == (tq & 3)) ? 1 : 0);
+      QDE2_TSTAMP(ts1);
+      if constexpr (QDE2_NBUF == 3) {
+        // at most ONE younger stage: its LPS row pieces, plus the strip if this wave loaded it -- three literals, two
+        // scalar branches (a general count through a switch costs a chain of ~40 scalar branches per stage: measured,
+        // 8 % of the kernel)
+        if (younger <= 0 || a.T < QDE2_NBUF) {
+          de_wait_vmcnt<0>();
+        } else {
+          const int tq = (t_dma == 0) ? a.T - 1 : t_dma - 1;       // in-group index of the youngest stage issued
+          if (wave == (tq & 3)) de_wait_vmcnt<C::LPS + 1>();
+          else de_wait_vmcnt<C::LPS>();
         }
+      } else {
+        de_wait_vmcnt<0>();     // (QDE2_NBUF == 2: nothing younger; deeper rings: conservative)
       }
-      de_wait_vmcnt_rt(keep);
+      QDE2_TSTAMP(ts2);
 #ifndef QDE_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
+#endif
+      QDE2_TSTAMP(ts3);
+#ifdef QDE2_STAMP_TURN
+      tt_lgkm += ts1 - ts0; tt_vm += ts2 - ts1; tt_bar += ts3 - ts2;
 #endif
 #ifdef QDE_ABL_NODMA
       if (false) {
@@ -435,7 +458,12 @@ __global__ __launch_bounds__(256, 1) void qde2_kernel(QDeArgs a) {
     qde_stamp(tk, rt);
     if (tid == 0) {
       a.stamps[2 * blockIdx.x] = tk - stamp_tk;
+#ifdef QDE2_STAMP_TURN
+      (void)rt;
+      a.stamps[2 * blockIdx.x + 1] = (tt_cal << 60) | ((tt_lgkm & 0xFFFFF) << 40) | ((tt_vm & 0xFFFFF) << 20) | (tt_bar & 0xFFFFF);
+#else
       a.stamps[2 * blockIdx.x + 1] = rt - stamp_rt;
+#endif
     }
   }
 }

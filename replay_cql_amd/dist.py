@@ -85,13 +85,26 @@ def reduce_scatter_sum(out: torch.Tensor, region: torch.Tensor, group=None, asyn
 
 
 def all_gather_into(full: torch.Tensor, mine: torch.Tensor, group=None, async_op: bool = False):
-    """full[r*n:(r+1)*n] = rank r's `mine` for every r (n = mine.numel())."""
+    """full[r*n:(r+1)*n] = rank r's `mine` for every r (n = mine.numel()).  `mine` must not alias `full` (the callers
+    pass a persistent staging buffer).  No device allocation on either backend: gloo gathers straight into views."""
     import torch.distributed as dist
     if dist.get_backend(group) == "nccl":
         return dist.all_gather_into_tensor(full, mine, group=group, async_op=async_op)
     w, n = dist.get_world_size(group), mine.numel()
-    parts = [torch.empty_like(mine) for _ in range(w)]
-    dist.all_gather(parts, mine, group=group)
-    for r in range(w):
-        full[r * n: (r + 1) * n].copy_(parts[r])
+    dist.all_gather([full[r * n: (r + 1) * n] for r in range(w)], mine, group=group)
     return None
+
+
+def shard_plan(off_E_in: int, off_E_out: int, off_W1: int, total: int, n_items: int, d: int, world: int, rank: int):
+    """Element ranges of the flat parameter buffer under the row-sharded optimizer (SURVEY 8(e), cfg5 variant):
+    R = n_items // world rows of E_in and of E_out per rank; what does not divide -- the last n_items - world * R rows,
+    the PAD row and alignment padding of E_in, b_out, the encoder -- stays replicated ("tails", all-reduced).
+    Pure arithmetic (tested on the CPU for world = 8 and n_items mod 8 != 0)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    n = (n_items // world) * d
+    return {"n": n,
+            "in_region": (off_E_in, off_E_in + world * n), "in_own": (off_E_in + rank * n, off_E_in + (rank + 1) * n),
+            "out_region": (off_E_out, off_E_out + world * n), "out_own": (off_E_out + rank * n, off_E_out + (rank + 1) * n),
+            "tail_in": (off_E_in + world * n, off_E_out), "tail_out": (off_E_out + world * n, off_W1),
+            "tail_enc": (off_W1, total)}

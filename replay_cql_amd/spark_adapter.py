@@ -10,14 +10,17 @@ pyspark / replay are imported lazily: `spark_adapter.CQL` resolves on first acce
 pyspark (duck-typed stand-ins for the DataFrame, the base class and the session).
 
 What the adapter does at the boundary, and where the reference does the same:
-  * `_fit`: ONE collect of the four LOG_SCHEMA columns -- as Arrow record batches when the DataFrame offers them
-    (`_collect_as_arrow`, what `toPandas()` itself uses under `spark.sql.execution.arrow.pyspark.enabled`,
-    replay/session_handler.py:47), else `toPandas()` exactly like NeuroMF._fit (replay/models/neuromf.py:332);
+  * `_fit`: ONE collect of the four LOG_SCHEMA columns through public API -- `DataFrame.toArrow()` where it exists
+    (PySpark >= 4.0: Arrow record batches, no pandas), else `toPandas()` exactly like NeuroMF._fit
+    (replay/models/neuromf.py:332; an Arrow collect under `spark.sql.execution.arrow.pyspark.enabled`,
+    replay/session_handler.py:47);
     the bookkeeping `_fit_wrap` computed (fit_users / fit_items / dims, base_rec.py:329-373) is handed to the inner
     model, which needs it for cold filtering, evaluate() and persistence.
   * `_predict`: scores ON THE DRIVER (GPU handles cannot be pickled into `applyInPandas` workers, cf.
     replay/models/base_torch_rec.py:132-148) and returns exactly-k, seen-filtered rows, so the wrapper's
-    `_filter_seen` + `get_top_k_recs` (base_rec.py:514-528) are passes over U*k rows that drop nothing.
+    `_filter_seen` + `get_top_k_recs` (base_rec.py:514-528) are passes over U*k rows that drop nothing.  The rows
+    leave as a `pyarrow.Table` through `createDataFrame` where the session takes one (PySpark >= 4.0), as a pandas
+    frame otherwise (base_torch_rec.py:143-148 returns pandas frames from its UDF too).
   * hyper-parameters are plain attributes (what `set_params`, base_rec.py:315-324, and optuna trials assign with
     setattr): they are forwarded to the inner model, `_init_args` reads them back (model_handler.save, :40-43), and
     `__init__` names every one of them explicitly because model_handler.load inspects the signature (:71-80).
@@ -31,25 +34,56 @@ import numpy as np
 
 from .cql import CQL as _ArrayCQL
 
+_ARROW_EGRESS: Dict[type, bool] = {}     # session type -> does createDataFrame take a pyarrow.Table?
+
 _HYPER = ("embedding_dim", "window", "batch_size", "epochs", "n_steps", "learning_rate", "gamma", "alpha", "tau", "seed",
           "predict_cold_users", "valid_split_size", "patience", "factor", "device", "checkpoint_dir")
 
 
+def _to_arrow_public(sel):
+    """`DataFrame.toArrow()` -- PUBLIC API since PySpark 4.0 -- as record batches, or None where the DataFrame has no such
+    method (PySpark 3.x: the reference pins 3.1.3)."""
+    to_arrow = getattr(sel, "toArrow", None)
+    if not callable(to_arrow):
+        return None
+    return to_arrow().to_batches()
+
+
 def _ids(df, column: str) -> np.ndarray:
     """distinct-id DataFrame (or anything `_get_ids` accepts downstream) -> numpy ids."""
-    return df.select(column).toPandas()[column].to_numpy()
+    sel = df.select(column)
+    batches = _to_arrow_public(sel)
+    if batches is not None:
+        return np.concatenate([b.column(0).to_numpy(zero_copy_only=False) for b in batches]) if batches \
+            else np.zeros(0, dtype=np.int64)
+    return sel.toPandas()[column].to_numpy()
+
+
+def _batch_to_pandas(rb):
+    """REC_SCHEMA record batch -> pandas: the egress of sessions that cannot take Arrow data (PySpark 3.x).  A function
+    of its own so that the Arrow-capable path can be shown never to call it (tests/test_spark_adapter.py)."""
+    return rb.to_pandas()
 
 
 def _collect_arrow(df, columns):
-    """The selected columns as Arrow record batches (no pandas materialisation) when the DataFrame can hand them over,
-    else as ONE batch made from toPandas()."""
+    """The selected columns as Arrow record batches through PUBLIC PySpark API only: `toArrow()` where the DataFrame has it
+    (PySpark >= 4.0: no pandas materialisation), else `toPandas()` -- itself an Arrow collect on the reference's session
+    (`spark.sql.execution.arrow.pyspark.enabled`, replay/session_handler.py:47) and exactly what NeuroMF._fit does
+    (replay/models/neuromf.py:332) -- wrapped into ONE batch.  PySpark 3.x's private `DataFrame._collect_as_arrow`
+    (what its toPandas() calls) skips the pandas copy there; it is used only on explicit request
+    (CQL_SPARK_PRIVATE_ARROW=1), never by default."""
+    import os
     import pyarrow as pa
     sel = df.select(*columns)
-    collect = getattr(sel, "_collect_as_arrow", None)
-    if callable(collect):
-        batches = collect()
-        if batches:
-            return batches
+    batches = _to_arrow_public(sel)
+    if batches:
+        return batches
+    if os.environ.get("CQL_SPARK_PRIVATE_ARROW") == "1":
+        collect = getattr(sel, "_collect_as_arrow", None)
+        if callable(collect):
+            batches = collect()
+            if batches:
+                return batches
     return [pa.RecordBatch.from_pandas(sel.toPandas(), preserve_index=False)]
 
 
@@ -116,13 +150,37 @@ def build_adapter(Recommender, State, REC_SCHEMA):
                 return State().session.createDataFrame(pdf)
             return State().session.createDataFrame(pdf, schema=schema)
 
+        def _recs_to_spark(self, rb):
+            """REC_SCHEMA record batch -> Spark DataFrame.  `SparkSession.createDataFrame(pyarrow.Table)` is public API
+            since PySpark 4.0 (the release that added `DataFrame.toArrow`): there the U x k block goes over as Arrow
+            data, no pandas in between.  Older sessions reject a Table with a TypeError (nothing was created): they get
+            the pandas frame, which PySpark 3.x converts through Arrow itself under the session flag
+            (replay/session_handler.py:47).  The answer is remembered per session type."""
+            import pyarrow as pa
+            session = State().session
+            key = type(session)
+            known = _ARROW_EGRESS.get(key)
+            if known is True:
+                return session.createDataFrame(pa.Table.from_batches([rb]), schema=REC_SCHEMA)
+            if known is None:           # first use with this kind of session: try, remember
+                try:
+                    out = session.createDataFrame(pa.Table.from_batches([rb]), schema=REC_SCHEMA)
+                    _ARROW_EGRESS[key] = True
+                    return out
+                except Exception as exc:  # pylint: disable=broad-except
+                    # PySpark 3.x: "TypeError: ... can not accept object ... pyarrow.lib.Table"; whatever it was, the pandas
+                    # route below re-raises a genuine failure
+                    _ARROW_EGRESS[key] = False
+                    self.logger.debug("createDataFrame(pyarrow.Table) not supported by this session (%r): pandas egress", exc)
+            return self._to_spark(_batch_to_pandas(rb), REC_SCHEMA)
+
         # pylint: disable=too-many-arguments
         def _predict(self, log, k, users, items, user_features=None, item_features=None, filter_seen_items=True):
             batches = None if log is None else _collect_arrow(
                 log, [c for c in ("user_idx", "item_idx", "timestamp") if c in log.columns])
             rb = self._impl.predict_arrow(batches, int(k), users=_ids(users, "user_idx"), items=_ids(items, "item_idx"),
                                           filter_seen_items=filter_seen_items)
-            return self._to_spark(rb.to_pandas(), REC_SCHEMA)
+            return self._recs_to_spark(rb)
 
         def _predict_pairs(self, pairs, log=None, user_features=None, item_features=None):
             if log is None:

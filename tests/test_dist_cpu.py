@@ -124,3 +124,81 @@ def test_reduce_scatter_and_all_gather_helpers_two_ranks():
     for rank, mine, full in res:
         assert np.array_equal(mine, total[rank * n: (rank + 1) * n])
         assert np.array_equal(full, 2 * total)
+
+
+def test_shard_plan_world8_with_remainder_rows():
+    """Row-sharded optimizer at world = 8 and N mod 8 != 0 (the cfg5 variant's arithmetic, never run on 8 GPUs here):
+    own slices tile the two regions, the three replicated tails tile the rest, nothing overlaps, nothing is left out."""
+    for n_items, d in ((1003, 64), (100_000, 128), (1_000_003, 256), (7, 64), (8, 128)):
+        lay = O.Layout.make(n_items, d)
+        plans = [PD.shard_plan(lay.off["E_in"], lay.off["E_out"], lay.off["W1"], lay.total, n_items, d, 8, r)
+                 for r in range(8)]
+        cover = np.zeros(lay.total, dtype=np.int32)
+        p0 = plans[0]
+        assert p0["n"] == (n_items // 8) * d
+        for key in ("in", "out"):
+            reg = p0[key + "_region"]
+            assert reg[1] - reg[0] == 8 * p0["n"]
+            for r, p in enumerate(plans):
+                assert p[key + "_region"] == reg
+                lo, hi = p[key + "_own"]
+                assert (lo, hi) == (reg[0] + r * p0["n"], reg[0] + (r + 1) * p0["n"])
+                cover[lo:hi] += 1
+        for key in ("tail_in", "tail_out", "tail_enc"):
+            lo, hi = p0[key]
+            assert hi >= lo
+            cover[lo:hi] += 1
+        assert np.all(cover == 1)
+        # the replicated E_in tail holds the last N mod 8 rows, the PAD row and the alignment padding
+        assert p0["tail_in"][1] - p0["tail_in"][0] >= ((n_items % 8) + 1) * d
+    with pytest.raises(ValueError):
+        PD.shard_plan(0, 10, 20, 30, 8, 1, 8, 8)
+
+
+def _plan8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    r, w, pg = PD.init_from_env("gloo")
+    n_items, d = 1003, 64
+    lay = O.Layout.make(n_items, d)
+    P = PD.shard_plan(lay.off["E_in"], lay.off["E_out"], lay.off["W1"], lay.total, n_items, d, world, rank)
+    g = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal(lay.total).astype(np.float32))
+    shadow = torch.zeros(lay.total, dtype=torch.bfloat16)
+    for key in ("in", "out"):          # reduce-scatter -> "Adam" on the own rows (here: bf16 of twice the sum) -> all-gather
+        reg, own = P[key + "_region"], P[key + "_own"]
+        mine = torch.empty(P["n"])
+        PD.reduce_scatter_sum(mine, g[reg[0]: reg[1]], pg)
+        stage = (2 * mine).to(torch.bfloat16)
+        PD.all_gather_into(shadow[reg[0]: reg[1]], stage, pg)
+    for key in ("tail_in", "tail_out", "tail_enc"):
+        lo, hi = P[key]
+        if hi > lo:
+            dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=pg)
+            shadow[lo:hi] = (2 * g[lo:hi]).to(torch.bfloat16)
+    q.put((rank, shadow.view(torch.int16).numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_exchange_eight_ranks_gloo():
+    """The exchange of the row-sharded optimizer rehearsed at world = 8 on the CPU backend, N mod 8 = 3: every rank ends
+    with the same full shadow, equal to the single-process result."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plan8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lay = O.Layout.make(1003, 64)
+    tot = np.zeros(lay.total, dtype=np.float32)
+    for r in range(world):          # gloo's all-reduce sums in rank order on every rank (ring of 8: not guaranteed);
+        tot += np.random.default_rng(100 + r).standard_normal(lay.total).astype(np.float32)
+    ref = torch.from_numpy(2 * tot).to(torch.bfloat16).float().numpy()
+    for rank, bits in res:
+        assert np.array_equal(bits, res[0][1])                       # identical on all ranks
+        got = torch.from_numpy(bits).view(torch.bfloat16).float().numpy()
+        np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=1e-6)   # one bf16 ulp: the sum order may differ

@@ -26,8 +26,9 @@ def _shard(off, items, rew, lo, hi):
     return off[lo: hi + 1] - off[lo], items[a:b], rew[a:b]
 
 
-def _worker(rank, world, port, theta0, q, shard=False, n_items=NI):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, theta0, q, shard=False, n_items=NI, exchange="allreduce"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      CQL_DP_EXCHANGE=exchange)
     import torch.distributed as dist
     from replay_cql_amd import dist as PD
     from replay_cql_amd.core import CQLCore, CQLHyper
@@ -43,8 +44,18 @@ def _worker(rank, world, port, theta0, q, shard=False, n_items=NI):
     losses = core.train(STEPS)            # world > 1 -> phased step with async all-reduce
     shadow = core.theta_b.view(torch.int16).cpu().numpy().copy()
     core.sync_full_state()                # no-op unless the optimizer is row-sharded
-    q.put((rank, core.theta.cpu().numpy(), losses.cpu().numpy(), shadow, core.adam_v.cpu().numpy(),
-           core.target.cpu().numpy()))
+    res = (rank, core.theta.cpu().numpy(), losses.cpu().numpy(), shadow, core.adam_v.cpu().numpy(),
+           core.target.cpu().numpy())
+    # the step loop allocates nothing once its persistent buffers exist: three more steps, allocation
+    # counters of the caching allocator unchanged
+    scratch = torch.zeros(4, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats()
+    core.train_steps(3, scratch)
+    torch.cuda.synchronize()
+    st1 = torch.cuda.memory_stats()
+    q.put(res + ((st1["allocation.all.allocated"] - st0["allocation.all.allocated"],
+                  st1["num_alloc_retries"] - st0["num_alloc_retries"]),))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,11 +66,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, theta0, shard=False, n_items=NI):
+def _run(world, theta0, shard=False, n_items=NI, exchange="allreduce"):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, theta0, q, shard, n_items)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, theta0, q, shard, n_items, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
@@ -86,6 +97,23 @@ def test_row_sharded_optimizer_equals_replicated(n_items):
     for k in (1, 4, 5):                                          # theta, adam_v, target after sync_full_state()
         assert np.array_equal(shd[0][k], shd[1][k]) and np.array_equal(shd[0][k], rep[0][k]), k
     assert np.array_equal(shd[0][2], rep[0][2])                  # same losses
+    for res in (rep, shd):                                       # allocation-free step loops, both variants, both ranks
+        for rk in res:
+            assert rk[6] == (0, 0), rk[6]
+
+
+def test_replicated_exchange_as_reduce_scatter_plus_all_gather():
+    """CQL_DP_EXCHANGE=rsag: the gradient sum of the replicated variant travels as reduce-scatter into a persistent
+    1/W shard + all-gather back.  Over gloo the helper's fallback forms the same sums as the all-reduce,
+    so the run must equal the all-reduce run bit for bit; replicas identical; no allocation in the loop."""
+    m = O.OracleModel.create(NI, D_, seed=7)
+    theta0 = m.theta.copy()
+    a = _run(2, theta0, exchange="allreduce")
+    b = _run(2, theta0, exchange="rsag")
+    for k in (1, 2, 3, 4, 5):
+        assert np.array_equal(b[0][k], b[1][k]) or k == 2, k
+        assert np.array_equal(a[0][k], b[0][k]), k
+    assert b[0][6] == (0, 0) and b[1][6] == (0, 0)
 
 
 def test_two_ranks_one_gpu_match_oracle():

@@ -58,12 +58,53 @@ class FakeDF:
 
 
 class FakeState:
+    """a PySpark-3.x-like session: createDataFrame takes pandas frames, not Arrow tables"""
     class _Session:
         @staticmethod
         def createDataFrame(pdf, schema=None):
+            if not isinstance(pdf, pd.DataFrame):
+                raise TypeError(f"StructType can not accept object {type(pdf).__name__}")
             if schema is not None:
                 assert list(pdf.columns) == list(schema)
             return FakeDF(pdf)
+    session = _Session()
+
+
+class ArrowDF(FakeDF):
+    """a PySpark-4-like DataFrame: public toArrow(); the private 3.x collect and toPandas() must stay unused"""
+    calls = []
+
+    def select(self, *cols):
+        return ArrowDF(self.pdf[list(cols)])
+
+    def distinct(self):
+        return ArrowDF(self.pdf.drop_duplicates())
+
+    def join(self, other, on, how="inner"):
+        return ArrowDF(self.pdf.merge(other.pdf, on=on, how=how))
+
+    def toArrow(self):
+        import pyarrow as pa
+        ArrowDF.calls.append("toArrow")
+        return pa.Table.from_pandas(self.pdf, preserve_index=False)
+
+    def _collect_as_arrow(self):
+        raise AssertionError("the adapter must not use PySpark's private _collect_as_arrow by default")
+
+
+class ArrowState:
+    """a PySpark-4-like session: createDataFrame(pyarrow.Table, schema) is public API"""
+    class _Session:
+        tables = []
+
+        @staticmethod
+        def createDataFrame(data, schema=None):
+            import pyarrow as pa
+            if isinstance(data, pa.Table):
+                assert schema is None or data.column_names == list(schema)
+                ArrowState._Session.tables.append(data)
+                return ArrowDF(data.to_pandas())
+            return ArrowDF(data)
     session = _Session()
 
 
@@ -71,6 +112,7 @@ class FakeRecommender:
     can_predict_cold_users = False
     can_predict_cold_items = False
     study = None
+    logger = __import__("logging").getLogger("replay")        # BaseRecommender.logger (base_rec.py:639-646)
 
     def set_params(self, **params):                       # base_rec.py:315-324
         for param, value in params.items():
@@ -164,6 +206,64 @@ def test_adapter_contract_without_gpu():
         m.no_such_attribute                                                     # noqa: B018
     with pytest.raises(RuntimeError, match="not fitted"):
         m._save_model("/nonexistent")
+
+
+def _rec_batch():
+    import pyarrow as pa
+    from replay_cql_amd.arrow_io import REC_SCHEMA as ARROW_REC
+    return pa.record_batch([pa.array([0, 0, 1], pa.int32()), pa.array([5, 7, 2], pa.int32()),
+                            pa.array([0.5, 0.25, 1.0], pa.float64())], schema=ARROW_REC)
+
+
+def test_arrow_capable_session_gets_arrow_tables_no_pandas(monkeypatch):
+    """f1, Spark half: on a session whose createDataFrame takes a pyarrow.Table (public API since PySpark
+    4.0) the recommendations leave as Arrow data -- the pandas conversion is never called -- and ingest goes through the
+    public DataFrame.toArrow(), never through the private _collect_as_arrow or toPandas()."""
+    from replay_cql_amd import spark_adapter as SA
+    monkeypatch.setattr(SA, "_batch_to_pandas", lambda rb: (_ for _ in ()).throw(AssertionError("to_pandas on the Arrow path")))
+    monkeypatch.setattr(ArrowDF, "toPandas", lambda self: (_ for _ in ()).throw(AssertionError("toPandas on the Arrow path")))
+    SA._ARROW_EGRESS.clear()
+    CQL4 = build_adapter(FakeRecommender, ArrowState, REC_SCHEMA)
+    m = CQL4(embedding_dim=64, window=4, batch_size=32, n_steps=1)
+    rb = _rec_batch()
+    for _ in range(2):                                   # second call: the remembered answer
+        ArrowState._Session.tables.clear()
+        out = m._recs_to_spark(rb)
+        assert len(ArrowState._Session.tables) == 1 and ArrowState._Session.tables[0].num_rows == 3
+        assert list(out.pdf.columns) == list(REC_SCHEMA)
+    # ingest: record batches from toArrow(); ids from toArrow()
+    log = ArrowDF(_log(U=5).pdf)
+    ArrowDF.calls.clear()
+    batches = SA._collect_arrow(log, ("user_idx", "item_idx", "timestamp", "relevance"))
+    assert ArrowDF.calls == ["toArrow"] and sum(b.num_rows for b in batches) == log.count()
+    assert batches[0].schema.names == ["user_idx", "item_idx", "timestamp", "relevance"]
+    ids = SA._ids(log.select("user_idx").distinct(), "user_idx")
+    assert sorted(ids.tolist()) == list(range(5))
+
+
+def test_pandas_only_session_falls_back_once(monkeypatch):
+    """a PySpark-3.x-like session rejects the Table: the adapter falls back to the pandas frame and does not try again"""
+    from replay_cql_amd import spark_adapter as SA
+    SA._ARROW_EGRESS.clear()
+    m = CQL(embedding_dim=64, window=4, batch_size=32, n_steps=1)
+    calls = []
+    real = FakeState._Session.createDataFrame
+    monkeypatch.setattr(FakeState._Session, "createDataFrame",
+                        staticmethod(lambda data, schema=None: (calls.append(type(data).__name__), real(data, schema))[1]))
+    out = m._recs_to_spark(_rec_batch())
+    assert calls == ["Table", "DataFrame"] and out.count() == 3
+    out = m._recs_to_spark(_rec_batch())
+    assert calls == ["Table", "DataFrame", "DataFrame"]
+    # the 3.x private collect is opt-in only: by default a DataFrame without toArrow() is collected with toPandas()
+    class Df3(FakeDF):
+        def select(self, *cols):
+            return Df3(self.pdf[list(cols)])
+
+        def _collect_as_arrow(self):
+            raise AssertionError("private API used without CQL_SPARK_PRIVATE_ARROW=1")
+    monkeypatch.delenv("CQL_SPARK_PRIVATE_ARROW", raising=False)
+    b = SA._collect_arrow(Df3(_log(U=3).pdf), ("user_idx", "item_idx"))
+    assert len(b) == 1 and b[0].num_columns == 2
 
 
 @pytest.fixture(scope="module")
