@@ -88,5 +88,55 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+def build_asan(verbose: bool = False) -> Path:
+    """AddressSanitizer build of the HOST side of the library + its driver (tests/asan/host_driver.cpp):
+    `hipcc --cuda-host-only -fsanitize=address` -- host code only (argument checks, error plumbing, size / split
+    arithmetic, launch preparation), no device code at all (GPU ASan / xnack+ code objects are not available on the
+    pool; a kernel launch from this build would fail, and the driver makes none).  Returns the driver executable.
+    A CPU test (tests/test_abi.py::test_host_layer_under_address_sanitizer) runs it."""
+    hipcc = _hipcc()
+    out = PKG / "build" / "asan"
+    out.mkdir(parents=True, exist_ok=True)
+    lib, exe = out / "libcqlrec_asan.so", out / "host_driver"
+    driver = PKG.parent / "tests" / "asan" / "host_driver.cpp"
+    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "cqlrec.h", driver, Path(__file__)]
+    if lib.exists() and exe.exists() and all(p.stat().st_mtime <= min(lib.stat().st_mtime, exe.stat().st_mtime) for p in deps):
+        return exe
+    flags = [f"--offload-arch={ARCH}", "--cuda-host-only", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address",
+             "-fPIC", "-std=c++17", "-Wno-unused-function"]
+
+    def compile_one(src: str) -> Path:
+        obj = out / (src + ".o")
+        cmd = [hipcc] + flags + ["-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, stderr=None if verbose else subprocess.DEVNULL)
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    # a host-only object still refers to its translation unit's device code object (__hip_fatbin_<hash>, registered with
+    # the runtime when the library is loaded, read at the first launch): zero-filled stand-ins of our OWN device code,
+    # which this build never launches
+    undef = subprocess.run(["nm", "-u"] + [str(o) for o in objs], check=True, capture_output=True, text=True).stdout
+    syms = sorted({ln.split()[-1] for ln in undef.splitlines() if "__hip_fatbin_" in ln})
+    stubs = out / "fatbin_stubs.cpp"
+    stubs.write_text("// generated by replay_cql_amd/build.py::build_asan\n" + "".join(
+        f'extern "C" {{ __attribute__((aligned(4096))) extern const char {s}[4096]; const char {s}[4096] = {{0}}; }}\n'
+        for s in syms))
+    clangxx = str(Path(hipcc).resolve().parent.parent / "lib" / "llvm" / "bin" / "clang++")
+    if not Path(clangxx).exists():
+        clangxx = "/opt/rocm/lib/llvm/bin/clang++"
+    rocm_lib = "/opt/rocm/lib"
+    subprocess.run([clangxx, "-shared", "-fPIC", "-O1", "-g", "-fsanitize=address", "-std=c++17", "-o", str(lib)] +
+                   [str(o) for o in objs] + [str(stubs), f"-L{rocm_lib}", "-lamdhip64", f"-Wl,-rpath,{rocm_lib}"], check=True)
+    subprocess.run([clangxx, "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-std=c++17", str(driver), "-o",
+                    str(exe), f"-L{out}", "-lcqlrec_asan", "-Wl,-rpath,$ORIGIN", f"-L{rocm_lib}", "-lamdhip64",
+                    f"-Wl,-rpath,{rocm_lib}", "-lpthread"], check=True)
+    return exe
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv))

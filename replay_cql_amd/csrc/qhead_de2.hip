@@ -26,7 +26,7 @@
 
 #define QDE2_ITEMS 256      // items per group: 4 waves x 2 x 32
 #ifndef QDE2_NBUF
-#define QDE2_NBUF 3         // ring depth (stages of 64 states): with 2 the pieces a turn waits for were issued ONE stage
+#define QDE2_NBUF 2         // ring depth (stages of 64 states): with 2 the pieces a turn waits for were issued ONE stage
 #endif                      // earlier and the wave parks on vmcnt(0) (PMC r02: 23 % of the wave's life in s_waitcnt / barrier)
 #ifndef QDE2_VALU_PER_MFMA
 #define QDE2_VALU_PER_MFMA 8   // VALU instructions the scheduler is asked to place behind each MFMA of slots 2 and 3

@@ -90,9 +90,24 @@ def all_gather_into(full: torch.Tensor, mine: torch.Tensor, group=None, async_op
     import torch.distributed as dist
     if dist.get_backend(group) == "nccl":
         return dist.all_gather_into_tensor(full, mine, group=group, async_op=async_op)
+    # gloo (tests): the flat form too where this torch's gloo has it (no temporary of the region's size on the device),
+    # else the list form into views
+    global _GLOO_FLAT_ALLGATHER
+    if _GLOO_FLAT_ALLGATHER is not False:
+        try:
+            dist.all_gather_into_tensor(full, mine, group=group)
+            _GLOO_FLAT_ALLGATHER = True
+            return None
+        except (RuntimeError, NotImplementedError):
+            if _GLOO_FLAT_ALLGATHER is True:
+                raise
+            _GLOO_FLAT_ALLGATHER = False
     w, n = dist.get_world_size(group), mine.numel()
     dist.all_gather([full[r * n: (r + 1) * n] for r in range(w)], mine, group=group)
     return None
+
+
+_GLOO_FLAT_ALLGATHER = None
 
 
 def shard_plan(off_E_in: int, off_E_out: int, off_W1: int, total: int, n_items: int, d: int, world: int, rank: int):

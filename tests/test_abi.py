@@ -1,6 +1,7 @@
 """The C-ABI library loads on a CPU-only box and exports every symbol include/cqlrec.h declares; host-only entry points
 (layout, workspace sizes, argument validation) behave.  No compute call is made here."""
 import ctypes as C
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -95,3 +96,18 @@ def test_product_path_never_imports_oracle():
     for f in (ROOT / "replay_cql_amd").glob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_host_layer_under_address_sanitizer():
+    """SURVEY 5 / VERDICT r2 missing #6: the host C++ side of the library (argument checks, error plumbing, size, split and
+    layout arithmetic of every entry point) built with -fsanitize=address and driven without a GPU
+    (replay_cql_amd/build.py::build_asan, tests/asan/host_driver.cpp: host-only objects, no device code -- GPU ASan is
+    not available on the pool).  Pass = exit code 0, the driver's "ok", no AddressSanitizer report."""
+    import subprocess
+    from replay_cql_amd import build as B
+    exe = B.build_asan()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1:verbosity=1", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert "AddressSanitizer Init done" in r.stderr, "the driver is not an ASan build"
+    assert r.returncode == 0 and "host_driver: ok" in r.stdout, r.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "ERROR: LeakSanitizer" not in r.stderr, r.stderr[-3000:]
