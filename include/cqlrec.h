@@ -297,6 +297,21 @@ int cqlrec_train_steps(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step0,
  * with events on `stream`.  0: strict program order on `stream` -- use it when timing individual kernels. */
 int cqlrec_set_concurrency(int32_t on);
 
+/* The step driver's internal side streams and events of the CURRENT device, created NOW instead of at the first
+ * training step, plus CQLREC_AUX_STREAMS library-owned streams for the caller's own side work (the predict pass's
+ * encoder stream, the data-parallel loop's item-side stream: cqlrec_aux_stream(i), i < CQLREC_AUX_STREAMS; NULL before
+ * cqlrec_runtime_init or for a bad index).  WHY IT MATTERS (measured, tools/stream_order_probe.py): the HIP runtime
+ * gives each of the first GPU_MAX_HW_QUEUES streams of a process a hardware queue of its own and lets every later
+ * stream SHARE the least-referenced queue -- typically the default stream's.  A process that creates other streams
+ * first (one torch.cuda.Stream() creates a pool of 64; torch.distributed's RCCL streams come from it) leaves the
+ * step driver's streams sharing ONE queue with the caller's stream, and the step loses all of its concurrency
+ * (cfg3: 1.33 instead of 0.69 ms per step).  Call this once per device right after selecting the device and before
+ * anything else creates streams (replay_cql_amd does, on import of its core); idempotent; needs a visible GPU.
+ * No reference counterpart (the reference trains on one stream, replay/models/base_torch_rec.py:57-98). */
+#define CQLREC_AUX_STREAMS 2
+int cqlrec_runtime_init(void);
+cqlrec_stream cqlrec_aux_stream(int32_t index);
+
 /* Debug/inspection of the intermediates of step `step` inside ctx->ws (device pointers; valid after that step's
  * fwd_bwd, until step+2 overwrites them: the per-step vectors are double-buffered by step parity). */
 typedef struct cqlrec_train_views {

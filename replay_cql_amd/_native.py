@@ -9,6 +9,12 @@ import os
 from pathlib import Path
 from typing import Optional
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step driver runs four
+# streams concurrently (the caller's + three internal), the predict pass and the data-parallel loop one more each: ask
+# for eight -- effective when this module is imported before the first HIP call of the process (importing torch makes
+# none); an explicit setting of the user's wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # CQLREC_LIB: another build of the same library (A/B-ing kernel variants with tools/); default: the in-tree build
 _LIB_PATH = Path(os.environ["CQLREC_LIB"]).resolve() if os.environ.get("CQLREC_LIB") else \
     Path(__file__).resolve().parent / "libcqlrec.so"
@@ -97,6 +103,8 @@ SIGNATURES = {
     "cqlrec_train_step_backward_rest": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),
     "cqlrec_set_concurrency": (i32, [i32]),
+    "cqlrec_runtime_init": (i32, []),
+    "cqlrec_aux_stream": (vp, [i32]),
     "cqlrec_qhead_fused_ws_bytes": (i64, [i64, i64, i32]),
     "cqlrec_qhead_fwd_lse_dh": (i32, [vp, i64, vp, vp, i64, i32, vp, i64, vp, vp, vp]),
     "cqlrec_qhead_dh_finish": (i32, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_float, vp, vp]),
@@ -156,6 +164,34 @@ def load() -> C.CDLL:
         raise CqlrecError(f"libcqlrec ABI {lib.cqlrec_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = lib
     return lib
+
+
+AUX_STREAMS = 2
+_aux_cache: dict = {}
+
+
+def runtime_init() -> None:
+    """Create the library's streams for the CURRENT device now (cqlrec_runtime_init: why the order of stream creation in
+    a process decides whether the training step keeps its concurrency).  CQLCore calls this on construction; a
+    data-parallel job calls it right after torch.cuda.set_device and BEFORE torch.distributed.init_process_group, whose
+    RCCL streams come out of torch's 64-stream pool."""
+    check(load().cqlrec_runtime_init(), "runtime_init")
+
+
+def aux_stream(index: int):
+    """Library-owned side stream `index` of the current device as a torch stream object (torch.cuda.ExternalStream):
+    side work of the host driver goes there instead of onto a torch.cuda.Stream(), whose first construction creates a
+    pool of 64 HIP streams."""
+    import torch  # pylint: disable=import-outside-toplevel
+    runtime_init()
+    dev = torch.cuda.current_device()
+    key = (dev, int(index))
+    if key not in _aux_cache:
+        ptr = load().cqlrec_aux_stream(int(index))
+        if not ptr:
+            raise CqlrecError(f"no aux stream {index}")
+        _aux_cache[key] = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", dev))
+    return _aux_cache[key]
 
 
 def check(rc: int, what: str = "") -> None:

@@ -54,6 +54,8 @@ class CQLCore:
             raise N.CqlrecError("CQLCore needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.hyper = hyper or CQLHyper()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        with torch.cuda.device(self.device):
+            N.runtime_init()          # the library's streams first: see cqlrec_runtime_init in include/cqlrec.h
         self.rank, self.world, self.pg = int(rank), int(world), process_group
         self.n_items = int(n_items)
         self.layout = N.make_layout(self.n_items, self.hyper.d)
@@ -234,7 +236,8 @@ class CQLCore:
         lo_a, hi_a, total = int(lay.off_E_out), int(lay.off_W1), int(lay.total)
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            with torch.cuda.device(self.device):
+                self._side = N.aux_stream(0)          # library-owned (never a torch.cuda.Stream(): see _native.aux_stream)
             self._ev = [torch.cuda.Event() for _ in range(3)]       # forward done, state-side backward done, items ready
         side = self._side
         ev_fwd, ev_rest, ev_items = self._ev
@@ -305,7 +308,8 @@ class CQLCore:
         c, s, P = self._train_ctx(), _stream(), self._shard_plan()
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            with torch.cuda.device(self.device):
+                self._side = N.aux_stream(0)
             self._ev = [torch.cuda.Event() for _ in range(3)]
         if self._gshard is None:
             self._gshard = (torch.empty(P["n"], dtype=torch.float32, device=self.device),
@@ -560,7 +564,8 @@ class CQLCore:
             # of the chunk before -- CQLREC_TOPK_SEEN_BESIDE, two workspaces: the HBM-bound bitmap slows the scoring
             # kernel by what it would cost alone; bitmap beside the encoder only: 2.19 ms per chunk, this order 2.0.)
             if self._topk_side is None:
-                self._topk_side = torch.cuda.Stream(device=self.device)
+                with torch.cuda.device(self.device):
+                    self._topk_side = N.aux_stream(1)
             side = self._topk_side
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
             bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]

@@ -158,6 +158,7 @@ struct SideStream {
   hipStream_t s = nullptr;    // sort of the gather backward (forward phase), item-side backward (backward phase)
   hipStream_t s2 = nullptr;   // branch B of the forward (s' rows: argmax + target network)
   hipStream_t s3 = nullptr;   // sampling + sorts of the NEXT step (cqlrec_train_steps)
+  hipStream_t aux[CQLREC_AUX_STREAMS] = {};   // handed to the caller (cqlrec_aux_stream)
   hipEvent_t sorted[2] = {nullptr, nullptr};   // sorted pairs of the step with this parity are in place
   hipEvent_t forked = nullptr, fork2 = nullptr, join2 = nullptr;
   hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr, bpro = nullptr, fwd_done = nullptr;
@@ -200,14 +201,19 @@ SideStream& side_stream() {
   return ss;
 }
 
-// streams created on first use: s (sorts of the forward; item side of the single-rank drivers) and s3 (sample-ahead of
-// cqlrec_train_steps only -- a data-parallel job never gets one)
+// streams created on first use -- or ahead of time by cqlrec_runtime_init, which is what keeps them on hardware queues of
+// their own (see cqlrec.h): s (sorts of the forward; item side of the single-rank drivers) and s3 (sample-ahead of
+// cqlrec_train_steps only)
 bool need_side_streams(SideStream& ss, bool want_s3 = false) {
   if (!ss.ok) return false;
   if (!ss.s && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
   if (ss.ok && want_s3 && !ss.s3 && hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
   return ss.ok;
 }
+
+// aux streams live beside the per-device side streams but do not depend on CQL_CONCURRENCY
+hipStream_t g_aux[CQL_MAX_DEVICES][CQLREC_AUX_STREAMS] = {};
+bool g_runtime_init[CQL_MAX_DEVICES] = {};
 
 struct StepPtrs {
   const uint16_t *Ein_b, *Eout_b, *W1_b, *W2_b, *tEin_b, *tEout_b, *tW1_b, *tW2_b;
@@ -227,6 +233,53 @@ StepPtrs step_ptrs(const cqlrec_train_ctx* c) {
   return p;
 }
 }  // namespace
+
+extern "C" int cqlrec_runtime_init(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+    cql_set_error("runtime_init: no HIP device");
+    return CQLREC_ERR_HIP;
+  }
+  const int slot = cql_device_slot();
+  if (g_runtime_init[slot]) return CQLREC_OK;
+  // order of creation = order in which hardware queues are handed out: the step driver's three first, then the caller's
+  if (concurrency_on()) {
+    SideStream& ss = side_stream();
+    if (!need_side_streams(ss, true)) {
+      cql_set_error("runtime_init: creating the internal streams failed");
+      return CQLREC_ERR_HIP;
+    }
+    // a stream's hardware queue is bound when it is first used: one empty marker each
+    for (hipStream_t st : {ss.s, ss.s2, ss.s3})
+      if (hipEventRecord(ss.forked, st) != hipSuccess) {
+        cql_set_error("runtime_init: hipEventRecord failed");
+        return CQLREC_ERR_HIP;
+      }
+  }
+  for (int i = 0; i < CQLREC_AUX_STREAMS; ++i) {
+    if (!g_aux[slot][i] && hipStreamCreateWithFlags(&g_aux[slot][i], hipStreamNonBlocking) != hipSuccess) {
+      cql_set_error("runtime_init: creating aux stream %d failed", i);
+      return CQLREC_ERR_HIP;
+    }
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+      (void)hipEventRecord(e, g_aux[slot][i]);
+      (void)hipEventDestroy(e);
+    }
+  }
+  if (hipDeviceSynchronize() != hipSuccess) {
+    cql_set_error("runtime_init: hipDeviceSynchronize failed");
+    return CQLREC_ERR_HIP;
+  }
+  g_runtime_init[slot] = true;
+  return CQLREC_OK;
+}
+
+extern "C" cqlrec_stream cqlrec_aux_stream(int32_t index) {
+  if (index < 0 || index >= CQLREC_AUX_STREAMS) return nullptr;
+  return (cqlrec_stream)g_aux[cql_device_slot()][index];
+}
+
 
 #define CQL_HIP_TRY(expr, what)                 \
   do {                                          \

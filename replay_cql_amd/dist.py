@@ -28,6 +28,11 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kwargs = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    if torch.cuda.is_available():
+        # the library's streams before RCCL's (cqlrec_runtime_init, include/cqlrec.h): on the device the caller selected
+        from . import _native as N
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            N.runtime_init()
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world, dist.group.WORLD
