@@ -229,7 +229,8 @@ def main():
     # the library's streams are created BEFORE torch.distributed creates RCCL's (cqlrec_runtime_init, include/cqlrec.h:
     # streams created late share the default stream's hardware queue and the step loses its concurrency)
     from replay_cql_amd import _native as N
-    N.runtime_init()
+    if not os.environ.get("CQL_SKIP_EARLY_INIT"):
+        N.runtime_init()
     pg = None
     if world > 1:
         import torch.distributed as dist

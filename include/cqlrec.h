@@ -297,19 +297,24 @@ int cqlrec_train_steps(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step0,
  * with events on `stream`.  0: strict program order on `stream` -- use it when timing individual kernels. */
 int cqlrec_set_concurrency(int32_t on);
 
-/* The step driver's internal side streams and events of the CURRENT device, created NOW instead of at the first
- * training step, plus CQLREC_AUX_STREAMS library-owned streams for the caller's own side work (the predict pass's
- * encoder stream, the data-parallel loop's item-side stream: cqlrec_aux_stream(i), i < CQLREC_AUX_STREAMS; NULL before
- * cqlrec_runtime_init or for a bad index).  WHY IT MATTERS (measured, tools/stream_order_probe.py): the HIP runtime
- * gives each of the first GPU_MAX_HW_QUEUES streams of a process a hardware queue of its own and lets every later
- * stream SHARE the least-referenced queue -- typically the default stream's.  A process that creates other streams
- * first (one torch.cuda.Stream() creates a pool of 64; torch.distributed's RCCL streams come from it) leaves the
- * step driver's streams sharing ONE queue with the caller's stream, and the step loses all of its concurrency
- * (cfg3: 1.33 instead of 0.69 ms per step).  Call this once per device right after selecting the device and before
- * anything else creates streams (replay_cql_amd does, on import of its core); idempotent; needs a visible GPU.
+/* The step driver's internal side streams and events of the CURRENT device, chosen and created NOW instead of at the
+ * first training step, plus CQLREC_AUX_STREAMS library-owned streams for the caller's own side work:
+ * cqlrec_aux_stream(0) = the data-parallel loop's item-side stream (the stream cqlrec_train_steps uses for its
+ * sample-ahead, which a phased caller never runs), cqlrec_aux_stream(1) = the predict pass's encoder stream; NULL before
+ * cqlrec_runtime_init or for a bad index.
+ * WHY (measured on MI355X / ROCm 7.2: tools/probes/pipe_probe.hip, tools/stream_order_probe3.py): a process's hardware
+ * queues sit on the 4 compute pipes round-robin in the order in which its streams were first used, and while a grid
+ * larger than the chip is being handed out on one queue, no kernel of another queue ON THE SAME PIPE is dispatched.  The
+ * step runs four streams side by side; if two of them share a pipe -- which used to depend on what else the process had
+ * created streams for, and when -- the step loses its concurrency (cfg3: 1.33 instead of 0.69 ms per step).  So the
+ * library picks its streams by test: out of up to eight fresh candidates, three that block neither the DEFAULT stream (the
+ * stream the caller is expected to train on) nor each other.  One-time cost: a few milliseconds, a device
+ * synchronisation; CQL_PIPE_PROBE=0 skips the test.  cqlrec_runtime_probe_count: candidates examined (0: no test ran).
+ * Idempotent; needs a visible GPU; replay_cql_amd calls it when a model is constructed.
  * No reference counterpart (the reference trains on one stream, replay/models/base_torch_rec.py:57-98). */
 #define CQLREC_AUX_STREAMS 2
 int cqlrec_runtime_init(void);
+int cqlrec_runtime_probe_count(void);
 cqlrec_stream cqlrec_aux_stream(int32_t index);
 
 /* Debug/inspection of the intermediates of step `step` inside ctx->ws (device pointers; valid after that step's

@@ -104,6 +104,7 @@ SIGNATURES = {
     "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),
     "cqlrec_set_concurrency": (i32, [i32]),
     "cqlrec_runtime_init": (i32, []),
+    "cqlrec_runtime_probe_count": (i32, []),
     "cqlrec_aux_stream": (vp, [i32]),
     "cqlrec_qhead_fused_ws_bytes": (i64, [i64, i64, i32]),
     "cqlrec_qhead_fwd_lse_dh": (i32, [vp, i64, vp, vp, i64, i32, vp, i64, vp, vp, vp]),

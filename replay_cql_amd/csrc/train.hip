@@ -158,7 +158,6 @@ struct SideStream {
   hipStream_t s = nullptr;    // sort of the gather backward (forward phase), item-side backward (backward phase)
   hipStream_t s2 = nullptr;   // branch B of the forward (s' rows: argmax + target network)
   hipStream_t s3 = nullptr;   // sampling + sorts of the NEXT step (cqlrec_train_steps)
-  hipStream_t aux[CQLREC_AUX_STREAMS] = {};   // handed to the caller (cqlrec_aux_stream)
   hipEvent_t sorted[2] = {nullptr, nullptr};   // sorted pairs of the step with this parity are in place
   hipEvent_t forked = nullptr, fork2 = nullptr, join2 = nullptr;
   hipEvent_t loss = nullptr, items = nullptr, dh = nullptr, eout = nullptr, presample = nullptr, adam_in = nullptr, bpro = nullptr, fwd_done = nullptr;
@@ -172,18 +171,123 @@ bool concurrency_on() {
   }
   return g_concurrency != 0;
 }
+// ---- which streams may run beside each other -----------------------------------------------------------------------------
+// Measured on MI355X / ROCm 7.2 (tools/probes/pipe_probe.hip, profiles/r03_pipe_probe.txt): a process's hardware queues sit
+// on the 4 compute pipes round-robin in the order in which its streams were first used, and while a grid larger than the
+// chip is being handed out on one queue, NO kernel of another queue on the same pipe is dispatched.  The step driver runs
+// four streams side by side (the caller's + three); whether two of them share a pipe used to depend on what else the
+// process had created streams for, and in which order -- a torch.cuda.Stream() between the log generation and the first
+// step, or the model constructed before the first kernel on the default stream, cost the step ALL of its concurrency
+// (cfg3: 1.33 instead of 0.69 ms; tools/stream_order_probe3.py).  So the streams are CHOSEN: out of a handful of fresh
+// candidates, three that block neither the caller's (default) stream nor each other, by the same two-kernel test.
+__global__ __launch_bounds__(64) void cql_pipe_hog_kernel(int spins) {
+  extern __shared__ volatile char pad[];      // 60 KiB of dynamic LDS: two blocks per CU resident, the rest of the grid waits
+  pad[threadIdx.x] = 1;
+  for (int i = 0; i < spins; ++i) __builtin_amdgcn_s_sleep(127);
+  pad[threadIdx.x + 64] = pad[threadIdx.x];
+}
+__global__ void cql_pipe_tiny_kernel() {}
+
+struct PipeProbe {
+  hipEvent_t a0 = nullptr, a1 = nullptr, b1 = nullptr;
+  bool ok = false;
+  PipeProbe() {
+    ok = hipEventCreate(&a0) == hipSuccess && hipEventCreate(&a1) == hipSuccess && hipEventCreate(&b1) == hipSuccess;
+  }
+  ~PipeProbe() {
+    if (a0) (void)hipEventDestroy(a0);
+    if (a1) (void)hipEventDestroy(a1);
+    if (b1) (void)hipEventDestroy(b1);
+  }
+  // 1: a kernel on y is not dispatched while a large grid on x is being handed out; 0: it is; -1: the test failed
+  int conflict(hipStream_t x, hipStream_t y) {
+    if (!ok || hipDeviceSynchronize() != hipSuccess) return -1;
+    (void)hipEventRecord(a0, x);
+    hipLaunchKernelGGL(cql_pipe_hog_kernel, dim3(8192), dim3(64), 60 * 1024, x, 3);     // ~0.2 ms
+    (void)hipEventRecord(a1, x);
+    hipLaunchKernelGGL(cql_pipe_tiny_kernel, dim3(1), dim3(64), 0, y);
+    (void)hipEventRecord(b1, y);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return -1;
+    float t_hog = 0.f, t_tiny = 0.f;
+    if (hipEventElapsedTime(&t_hog, a0, a1) != hipSuccess || hipEventElapsedTime(&t_tiny, a0, b1) != hipSuccess) return -1;
+    return (t_hog > 0.02f && t_tiny > 0.5f * t_hog) ? 1 : 0;
+  }
+};
+
+hipStream_t g_aux[CQL_MAX_DEVICES][CQLREC_AUX_STREAMS] = {};
+int g_pick_report[CQL_MAX_DEVICES] = {};     // candidates looked at (0: no probe ran), for cqlrec_runtime_report
+
+// three streams for the step driver + one more for the caller, all first used HERE, in this order
+bool pick_streams(hipStream_t main, hipStream_t out[3], hipStream_t* extra, int* looked_at) {
+  constexpr int NC = 8;
+  static const bool probe_on = !(getenv("CQL_PIPE_PROBE") && getenv("CQL_PIPE_PROBE")[0] == '0');
+  hipStream_t cand[NC] = {};
+  bool used[NC] = {};
+  int n_out = 0;
+  *looked_at = 0;
+  hipLaunchKernelGGL(cql_pipe_tiny_kernel, dim3(1), dim3(64), 0, main);       // the caller's queue exists first
+  PipeProbe pp;
+  int made = 0;
+  for (; made < NC && n_out < 3; ++made) {
+    if (hipStreamCreateWithFlags(&cand[made], hipStreamNonBlocking) != hipSuccess) break;
+    hipLaunchKernelGGL(cql_pipe_tiny_kernel, dim3(1), dim3(64), 0, cand[made]);   // binds its queue now: creation order
+    bool good = true;
+    if (probe_on && pp.ok) {
+      *looked_at = made + 1;
+      good = pp.conflict(main, cand[made]) == 0;
+      for (int k = 0; good && k < n_out; ++k) good = pp.conflict(out[k], cand[made]) == 0;
+    }
+    if (good) {
+      out[n_out++] = cand[made];
+      used[made] = true;
+    }
+  }
+  // not enough independent ones (queues exhausted, probe failed): take what there is, as before
+  for (int i = 0; i < made && n_out < 3; ++i)
+    if (!used[i]) {
+      out[n_out++] = cand[i];
+      used[i] = true;
+    }
+  while (n_out < 3) {
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    out[n_out++] = st;
+  }
+  // the caller's extra stream: an unused candidate that does not block the caller's main stream, else a fresh one
+  *extra = nullptr;
+  for (int i = 0; i < made; ++i)
+    if (!used[i] && !*extra && (!probe_on || !pp.ok || pp.conflict(main, cand[i]) == 0)) {
+      *extra = cand[i];
+      used[i] = true;
+    }
+  for (int i = 0; i < made; ++i)
+    if (!used[i]) (void)hipStreamDestroy(cand[i]);
+  if (!*extra && hipStreamCreateWithFlags(extra, hipStreamNonBlocking) != hipSuccess) return false;
+  return hipDeviceSynchronize() == hipSuccess;
+}
+
 SideStream& side_stream() {
   static SideStream per_device[CQL_MAX_DEVICES];     // streams and events belong to the device they were created on
   static SideStream off;   // never ok: serial mode
   if (!concurrency_on()) return off;
-  SideStream& ss = per_device[cql_device_slot()];
+  const int slot = cql_device_slot();
+  SideStream& ss = per_device[slot];
   if (!ss.tried) {
     ss.tried = true;
-    // Plain streams, all of one priority class: mixing priority classes (tried: item-side backward low, branch stream
-    // high) did not steer the dispatcher, and with a fifth stream in the process (the caller's side stream in the
-    // data-parallel step) it serialised unrelated streams -- the phased step went from 0.28 to 0.64 ms at cfg2.
-    // s and s3 are created on first use (need_side_streams)
-    ss.ok = hipStreamCreateWithFlags(&ss.s2, hipStreamNonBlocking) == hipSuccess &&
+    // Plain streams, all of one priority class (mixing priority classes did not steer the dispatcher).  s2 = forward branch,
+    // s = sorts of the forward / item side of the single-rank drivers, s3 = sample-ahead of cqlrec_train_steps.  A
+    // data-parallel caller never runs cqlrec_train_steps: ITS item-side stream (cqlrec_aux_stream(0)) is s3.
+    hipStream_t pk[3] = {};
+    hipStream_t extra = nullptr;
+    ss.ok = pick_streams(nullptr, pk, &extra, &g_pick_report[slot]);
+    if (ss.ok) {
+      ss.s2 = pk[0];
+      ss.s = pk[1];
+      ss.s3 = pk[2];
+      if (!g_aux[slot][0]) g_aux[slot][0] = pk[2];      // (already set: runtime_init ran while the library was in serial mode)
+      if (!g_aux[slot][1]) g_aux[slot][1] = extra;
+    }
+    ss.ok = ss.ok &&
             hipEventCreateWithFlags(&ss.sorted[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.sorted[1], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ss.forked, hipEventDisableTiming) == hipSuccess &&
@@ -201,19 +305,11 @@ SideStream& side_stream() {
   return ss;
 }
 
-// streams created on first use -- or ahead of time by cqlrec_runtime_init, which is what keeps them on hardware queues of
-// their own (see cqlrec.h): s (sorts of the forward; item side of the single-rank drivers) and s3 (sample-ahead of
-// cqlrec_train_steps only)
+// (the three streams exist as soon as side_stream() has run)
 bool need_side_streams(SideStream& ss, bool want_s3 = false) {
-  if (!ss.ok) return false;
-  if (!ss.s && hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
-  if (ss.ok && want_s3 && !ss.s3 && hipStreamCreateWithFlags(&ss.s3, hipStreamNonBlocking) != hipSuccess) ss.ok = false;
+  (void)want_s3;
   return ss.ok;
 }
-
-// aux streams live beside the per-device side streams but do not depend on CQL_CONCURRENCY
-hipStream_t g_aux[CQL_MAX_DEVICES][CQLREC_AUX_STREAMS] = {};
-bool g_runtime_init[CQL_MAX_DEVICES] = {};
 
 struct StepPtrs {
   const uint16_t *Ein_b, *Eout_b, *W1_b, *W2_b, *tEin_b, *tEout_b, *tW1_b, *tW2_b;
@@ -241,39 +337,22 @@ extern "C" int cqlrec_runtime_init(void) {
     return CQLREC_ERR_HIP;
   }
   const int slot = cql_device_slot();
-  if (g_runtime_init[slot]) return CQLREC_OK;
-  // order of creation = order in which hardware queues are handed out: the step driver's three first, then the caller's
   if (concurrency_on()) {
-    SideStream& ss = side_stream();
-    if (!need_side_streams(ss, true)) {
+    if (!side_stream().ok) {
       cql_set_error("runtime_init: creating the internal streams failed");
       return CQLREC_ERR_HIP;
     }
-    // a stream's hardware queue is bound when it is first used: one empty marker each
-    for (hipStream_t st : {ss.s, ss.s2, ss.s3})
-      if (hipEventRecord(ss.forked, st) != hipSuccess) {
-        cql_set_error("runtime_init: hipEventRecord failed");
+  } else {      // strict program order inside the library: the caller's side streams are plain ones
+    for (int i = 0; i < CQLREC_AUX_STREAMS; ++i)
+      if (!g_aux[slot][i] && hipStreamCreateWithFlags(&g_aux[slot][i], hipStreamNonBlocking) != hipSuccess) {
+        cql_set_error("runtime_init: creating aux stream %d failed", i);
         return CQLREC_ERR_HIP;
       }
   }
-  for (int i = 0; i < CQLREC_AUX_STREAMS; ++i) {
-    if (!g_aux[slot][i] && hipStreamCreateWithFlags(&g_aux[slot][i], hipStreamNonBlocking) != hipSuccess) {
-      cql_set_error("runtime_init: creating aux stream %d failed", i);
-      return CQLREC_ERR_HIP;
-    }
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
-      (void)hipEventRecord(e, g_aux[slot][i]);
-      (void)hipEventDestroy(e);
-    }
-  }
-  if (hipDeviceSynchronize() != hipSuccess) {
-    cql_set_error("runtime_init: hipDeviceSynchronize failed");
-    return CQLREC_ERR_HIP;
-  }
-  g_runtime_init[slot] = true;
   return CQLREC_OK;
 }
+
+extern "C" int cqlrec_runtime_probe_count(void) { return g_pick_report[cql_device_slot()]; }
 
 extern "C" cqlrec_stream cqlrec_aux_stream(int32_t index) {
   if (index < 0 || index >= CQLREC_AUX_STREAMS) return nullptr;

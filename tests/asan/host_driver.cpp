@@ -107,6 +107,9 @@ static void refused_calls() {
   EXPECT(cqlrec_prof_select(0xFFFFFFFFu) == CQLREC_OK);
   EXPECT(cqlrec_set_concurrency(1) == CQLREC_OK);
   EXPECT(cqlrec_abi_version() == CQLREC_ABI_VERSION);
+  EXPECT(cqlrec_aux_stream(-1) == nullptr && cqlrec_aux_stream(CQLREC_AUX_STREAMS) == nullptr);
+  EXPECT(cqlrec_aux_stream(0) == nullptr);       // before cqlrec_runtime_init (which needs a GPU)
+  EXPECT(cqlrec_runtime_probe_count() == 0);
 }
 
 // the error message buffer is thread-local: concurrent failing calls must not trample each other's text

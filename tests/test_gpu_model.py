@@ -242,23 +242,23 @@ def test_out_of_range_item_ids_raise_before_any_kernel(log, model):
     assert a == b
 
 
-def test_predict_before_fit_keeps_the_training_step_concurrent():
-    """r3 finding (tools/stream_order_probe.py): the HIP runtime gives the first GPU_MAX_HW_QUEUES streams of a process
-    hardware queues of their own and lets later ones share the default stream's -- a predict pass (which used to create
-    a torch side stream) BEFORE the first training step left the step driver's internal streams on ONE queue with the
-    caller's stream: 1.33 instead of 0.69 ms per step at cfg3.  The library now creates its streams when the model is
-    constructed (cqlrec_runtime_init) and hands its own side streams to the host driver.  Checked in fresh processes:
-    training after a predict pass (and after a torch stream created behind the model) is as fast as training alone."""
+def test_training_keeps_its_concurrency_whatever_the_process_did_before():
+    """r3 finding (tools/probes/pipe_probe.hip, tools/stream_order_probe3.py; include/cqlrec.h, cqlrec_runtime_init): hardware
+    queues sit on the 4 compute pipes in the order the process first used its streams, and two streams on one pipe cannot
+    have kernels DISPATCHED side by side -- the training step (four streams) ran 1.33 instead of 0.69 ms at cfg3 when the
+    model was constructed before the first kernel on the default stream, or when a torch.cuda.Stream() had been used
+    between the log generation and the first step.  The library now picks its streams by test.  Fresh processes, three
+    histories: the timed steps must cost the same."""
     import json
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     ms = {}
-    for mode in ("base", "predict_first", "torchstream_after_core"):
-        r = subprocess.run([sys.executable, str(root / "tools" / "stream_order_probe.py"), mode], capture_output=True,
+    for order in (("work", "core"), ("core", "work"), ("work", "tstream", "core"), ("tstream", "core", "work")):
+        r = subprocess.run([sys.executable, str(root / "tools" / "stream_order_probe3.py"), *order], capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        ms[mode] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
-    assert ms["predict_first"] < 1.25 * ms["base"], ms
-    assert ms["torchstream_after_core"] < 1.25 * ms["base"], ms
+        ms[" ".join(order)] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+    base = ms["work core"]
+    assert all(v < 1.2 * base for v in ms.values()), ms
