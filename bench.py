@@ -255,10 +255,11 @@ def main():
 
     def gen_log():
         return synth_log_device(U, NI, seed=12345, device=dev, user_lo=lo, user_hi=hi, **gen_kw)
-    # Order of the set-up (nothing of it is timed): the model FIRST -- its parameters are drawn on the host and uploaded,
-    # seconds during which the GPU idles -- and the log LAST, generated on the device right in front of the warm-up
-    # steps, so that the warm-up starts on a GPU that has just been working instead of one that has clocked down
-    # (tools/step_ramp.py: from idle the first ~30 steps run 3-15 % slower, whatever their number).
+    # Order of the set-up (nothing of it is timed): the model first -- its parameters are drawn on the host and uploaded --
+    # and the log last, generated on the device right in front of the warm-up steps.  (It does not shorten the ramp: the
+    # first ~30 steps of a process run 3-12 % slower than the steady state whatever the GPU did before them -- idle, 150 ms
+    # of GEMMs, a predict pass: tools/step_ramp.py, profiles/r03_step_ramp.json -- so `--steps 20 --warmup 5` reads ~5 %
+    # below `--steps 200 --warmup 20`; README quotes the former, the driver's condition.)
     # Ranks > 1, two exchange patterns with the same bytes on the links: "sharded" = reduce-scatter of the
     # gradients, Adam on this rank's rows only, all-gather of the bf16 shadows (1/W of the Adam traffic per GPU);
     # "allreduce" = replicated Adam behind a gradient all-reduce.  The variant is chosen by --dp-variant and the run
@@ -316,20 +317,6 @@ def main():
 
     if args.serial:
         N.check(lib.cqlrec_set_concurrency(0), "set_concurrency")
-    # The predict path's one-time work (workspace, side stream, LDS opt-ins of its kernels) is done HERE, by one untimed
-    # pass over this rank's users, rather than inside the top-K leg's first timed repetition.  It also means the W warm-up
-    # steps below start on a GPU that has been running this kind of load for tens of milliseconds: from idle -- or from any
-    # other load -- the chip's clock takes ~30 steps to settle (tools/step_ramp.py, profiles/r03_step_ramp.json), more
-    # than the 5 warm-up steps the driver passes.  Nothing moves out of the timed steps.
-    tk_state = None
-    if not args.no_topk:
-        nu_ = hi - lo
-        users_ = torch.arange(nu_, dtype=torch.int32, device=dev)
-        rows_ = torch.repeat_interleave(torch.arange(nu_, device=dev), off[1:] - off[:-1])
-        seen_items_ = items[torch.argsort(rows_ * NI + items.to(torch.int64))].contiguous()   # input preparation, untimed
-        del rows_
-        core.encode_topk(off, items, users_, K, seen=(off, seen_items_), chunk=min(cfg["topk_users"], nu_))
-        tk_state = (users_, seen_items_)
     run(args.warmup, 0)
     barrier()
     # Inside the timed region only the kernel the `roofline` object reports on is bracketed with HIP events: every event pair costs two barrier packets on its stream, and bracketing all ~35
@@ -378,7 +365,11 @@ def main():
         # all users of this rank's shard, in chunks of cfg["topk_users"] (one launch of the scoring kernel each)
         nu = hi - lo
         tk_chunk = min(cfg["topk_users"], nu)
-        users, seen_items = tk_state      # seen lists = items sorted inside each user's row (prepared above, untimed)
+        users = torch.arange(nu, dtype=torch.int32, device=dev)
+        # seen lists = items sorted inside each user's row (input preparation, untimed)
+        rows = torch.repeat_interleave(torch.arange(hi - lo, device=dev), off[1:] - off[:-1])
+        seen_items = items[torch.argsort(rows * NI + items.to(torch.int64))].contiguous()
+        del rows
         core.encode_topk(off, items, users[:1024], K, seen=(off, seen_items), chunk=tk_chunk)      # warm-up
         barrier()
         t1 = time.perf_counter()
