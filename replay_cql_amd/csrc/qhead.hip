@@ -1053,7 +1053,10 @@ struct FusedWs {
 };
 static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
   FusedWs f;
-  f.sp = qs_choose_split(n_items, rows, QS_SPW_BWD, QS_TI, QS_TARGET_BLOCKS_BWD);
+  // item slices: 128-state row-blocks x slices = two blocks per CU for the generic form and for qfwd2_kernel (which halves
+  // the row-blocks: one block per CU); qfwd3_kernel (d = 256, 128 states per block, one block per CU resident) gets half as
+  // many, twice as long slices -- one round of blocks, half the slab traffic
+  f.sp = qs_choose_split(n_items, rows, QS_SPW_BWD, QS_TI, cql_qfwd3_supported(d, n_items) ? QS_TARGET_BLOCKS_BWD / 2 : QS_TARGET_BLOCKS_BWD);
   const int64_t slab_b = align256((int64_t)f.sp.nsplit * rows * d * 4), seg = align256((int64_t)f.sp.nsplit * rows * 4);
   f.slab = (float*)ws;
   f.part_a = (float*)((char*)ws + slab_b);
@@ -1066,7 +1069,7 @@ static FusedWs fused_ws(void* ws, int64_t rows, int64_t n_items, int32_t d) {
 // the overflow flag of the one-wave-per-SIMD form, cleared ahead of time: a caller whose catalogue pass waits for an event
 // (the item-side optimizer) clears it in front of that wait, off the critical path, and passes flag_cleared = 1
 int cql_qhead_fwd_lse_dh_prepare(void* ws, int64_t rows, int64_t n_items, int32_t d, hipStream_t s) {
-  if (!cql_qfwd2_supported(d, n_items)) return CQLREC_OK;
+  if (!cql_qfwd2_supported(d, n_items) && !cql_qfwd3_supported(d, n_items)) return CQLREC_OK;
   const FusedWs f = fused_ws(ws, rows, n_items, d);
   if (hipMemsetAsync(f.flag, 0, 4, s) != hipSuccess) {
     cql_set_error("qhead_fwd_lse_dh: hipMemsetAsync failed");
@@ -1095,8 +1098,8 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
   a.part_a = f.part_a;
   a.part_b = f.part_b;
   a.tg = 1;
-  if (cql_qfwd2_supported(d, n_items)) {
-    // one wave per SIMD, fixed per-slice reference (qhead_fwd2.hip); the first form follows, guarded by the flag the
+  if (cql_qfwd2_supported(d, n_items) || cql_qfwd3_supported(d, n_items)) {
+    // one wave per SIMD, fixed per-slice reference (qhead_fwd2.hip, qhead_fwd3.hip); the first form follows, guarded by the flag the
     // second sets when a partial sum overflowed -- its blocks return at once otherwise
     if (!flag_cleared && hipMemsetAsync(f.flag, 0, 4, s) != hipSuccess) {
       cql_set_error("qhead_fwd_lse_dh: hipMemsetAsync failed");
@@ -1116,7 +1119,7 @@ int cql_qhead_fwd_lse_dh(const uint16_t* H_b, int64_t rows, const uint16_t* E_ou
     a2.flag = f.flag;
     {
       CqlProfScope prof(CQLREC_PH_QHEAD_LSE, s);
-      const int rc = cql_qfwd2_run(a2, d, s);
+      const int rc = (d == 256) ? cql_qfwd3_run(a2, d, s) : cql_qfwd2_run(a2, d, s);
       if (rc != CQLREC_OK) return rc;
     }
     a.guard = f.flag;

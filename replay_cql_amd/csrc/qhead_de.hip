@@ -426,7 +426,8 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
   unsigned long long* stamps_dev = (unsigned long long*)((char*)a.slab_cs + de_align256((int64_t)grid * items * 4) +
                                                          de_align256(batch * 4));
   a.stamps = want_stamps ? stamps_dev : nullptr;
-  if (form2) {
+  const bool form3 = !form2 && cql_qde3_supported(d, batch);      // d = 256: same groups, stages and grid as qde_kernel<256>
+  if (form2 || form3) {
     if (nlse_nat) {        // the caller's forward already wrote -lse in natural units
       a.nlse2 = nlse_nat;
     } else {
@@ -438,7 +439,7 @@ int cql_qde_launch(const uint16_t* H_b, const float* nlse2, int64_t batch, const
       a.nlse2 = nat;
     }
     CqlProfScope prof(CQLREC_PH_QHEAD_BWD_DE, s);
-    const int rc = cql_qde2_run(a, d, grid, s);
+    const int rc = form2 ? cql_qde2_run(a, d, grid, s) : cql_qde3_run(a, d, grid, s);
     if (rc != CQLREC_OK) return rc;
   } else {
     CqlProfScope prof(CQLREC_PH_QHEAD_BWD_DE, s);

@@ -84,3 +84,6 @@ __device__ __forceinline__ void de_wait_vmcnt() {
 
 // qhead_de2.hip: 64 items per wave, one wave per SIMD (d = 64, 128).  `a.nlse2` holds -lse in NATURAL units there.
 int cql_qde2_run(const QDeArgs& a, int d, int grid, hipStream_t s);
+// qhead_de3.hip: 32 items per wave, one wave per SIMD, in-wave pipeline (d = 256).  -lse in NATURAL units as for qde2.
+bool cql_qde3_supported(int d, int64_t batch);
+int cql_qde3_run(const QDeArgs& a, int d, int grid, hipStream_t s);

@@ -139,3 +139,6 @@ struct QFwd2Args {
 };
 bool cql_qfwd2_supported(int d, int64_t n_items);
 int cql_qfwd2_run(const QFwd2Args& a, int d, hipStream_t s);
+// qhead_fwd3.hip: the same pass for d = 256 (one 32-state group per wave, 128 states per block)
+bool cql_qfwd3_supported(int d, int64_t n_items);
+int cql_qfwd3_run(const QFwd2Args& a, int d, hipStream_t s);

@@ -356,7 +356,8 @@ def test_qhead_bwd(lib, B, Nn, d):
 
 
 @pytest.mark.parametrize("B,Nn,d,ramp", [(32, 64, 64, 0.0), (50, 257, 64, 0.0), (128, 1000, 128, 0.0), (300, 4099, 128, 0.02),
-                                         (96, 513, 256, 0.0), (1024, 10007, 64, 0.0), (64, 20000, 128, 0.01)])
+                                         (96, 513, 256, 0.0), (1024, 10007, 64, 0.0), (64, 20000, 128, 0.01),
+                                         (300, 4099, 256, 0.02), (130, 20011, 256, 0.0), (1, 33, 256, 0.0)])
 def test_qhead_fused_forward_dh(lib, B, Nn, d, ramp):
     """One-pass forward (lse + softmax-weighted item sum relative to a running reference) + dh_finish == the
     two-pass definition: lse to 1e-5, dH to 3e-3 normwise (P is rounded to bf16 at a different scale).  `ramp` adds a
@@ -391,12 +392,11 @@ def test_qhead_fused_forward_dh(lib, B, Nn, d, ramp):
     assert np.abs(got - dH_ref).max() < 4e-3 * np.abs(dH_ref).max()
 
 
-@pytest.mark.parametrize("B,Nn", [(128, 1000), (300, 4099)])
-def test_qhead_fused_forward_overflow_falls_back(lib, B, Nn):
-    """d = 128: qfwd2_kernel fixes its reference from the first tile of every item slice.  A bias step of +200 nats
-    behind the first tile makes exp(S - ref) overflow there; the kernel flags it and the guarded first form redoes the
-    pass -- the result must be the exact one all the same."""
-    d = 128
+@pytest.mark.parametrize("B,Nn,d", [(128, 1000, 128), (300, 4099, 128), (128, 1000, 256), (300, 4099, 256)])
+def test_qhead_fused_forward_overflow_falls_back(lib, B, Nn, d):
+    """d = 128 / 256: qfwd2_kernel / qfwd3_kernel fix their reference from the first tile of every item slice.  A bias step
+    of +200 nats behind the first tile makes exp(S - ref) overflow there; the kernel flags it and the guarded first form
+    redoes the pass -- the result must be the exact one all the same."""
     Hb, Eb, b = _qhead_inputs(B, Nn, d, False, B + Nn + 3)
     Hb = O.bf16_round(Hb * 0.5)
     b = b.astype(np.float32)
