@@ -460,9 +460,10 @@ def main():
         dom = max(qk, key=qk.get)
         flops = 2.0 * B * NI * d          # algorithmic flops of ONE Q-head GEMM (8*B*N*d per step = 4 GEMMs)
         ach = gemms[dom] * flops / (qk[dom] * 1e-3) / 1e12
-        kname = {"qhead_lse": "qfwd2_kernel<128> (fused forward: lse + softmax-weighted item sum)" if d == 128
-                 else "qstream_kernel<QM_LSE_DH>",
-                 "qhead_bwd_de": ("qde2_kernel<128>" if (d == 128 and B % 64 == 0) else "qde_kernel") + " (item-side backward)",
+        kname = {"qhead_lse": ("qfwd2_kernel<128>" if d == 128 else "qfwd3_kernel<256>" if d == 256 else "qstream_kernel<QM_LSE_DH>")
+                 + " (fused forward: lse + softmax-weighted item sum)",
+                 "qhead_bwd_de": ("qde2_kernel<128>" if (d == 128 and B % 64 == 0) else "qde3_kernel<256>" if (d == 256 and B % 32 == 0)
+                                  else "qde_kernel") + " (item-side backward)",
                  "qhead_argmax": "qstream_kernel<QM_ARGMAX>"}.get(dom, dom)
         out["roofline"] = {"kernel": kname, "phase": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_ms": qk[dom],
@@ -472,8 +473,9 @@ def main():
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))          # a malformed file is an error, not a silent null
-            if pmc["config"] == {"batch": B, "items": NI, "d": d} and dom in pmc["kernels"]:
-                out["roofline"]["traffic"] = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            hit = [e for e in pmc["entries"] if e["config"] == {"batch": B, "items": NI, "d": d} and dom in e["kernels"]]
+            if hit:
+                out["roofline"]["traffic"] = hit[0]["kernels"][dom]["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = pmc["source"] + "; " + pmc["correction"]
             else:
                 out["roofline"]["traffic_note"] = "profiles/pmc_traffic.json holds no counters for this shape/kernel"
