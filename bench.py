@@ -464,7 +464,7 @@ def main():
                  + " (fused forward: lse + softmax-weighted item sum)",
                  "qhead_bwd_de": ("qde2_kernel<128>" if (d == 128 and B % 64 == 0) else "qde3_kernel<256>" if (d == 256 and B % 32 == 0)
                                   else "qde_kernel") + " (item-side backward)",
-                 "qhead_argmax": "qstream_kernel<QM_ARGMAX>"}.get(dom, dom)
+                 "qhead_argmax": "qargmax2_kernel<256>" if d == 256 else "qstream_kernel<QM_ARGMAX>"}.get(dom, dom)
         out["roofline"] = {"kernel": kname, "phase": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_ms": qk[dom],
                            "algorithmic_flops_per_launch": gemms[dom] * flops}

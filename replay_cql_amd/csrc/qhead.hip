@@ -845,11 +845,11 @@ extern "C" int64_t cqlrec_qhead_ws_bytes(int64_t rows, int64_t n_items, int32_t 
 
 static int qhead_fwd_impl(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                          int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx,
-                         float* out_nlse2, cqlrec_stream stream, bool small_waves);
+                         float* out_nlse2, cqlrec_stream stream, int form);
 extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out,
                                 int64_t n_items, int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val,
                                 int32_t* out_idx, float* out_nlse2, cqlrec_stream stream) {
-  return qhead_fwd_impl(H_b, rows, E_out_b, b_out, n_items, d, mode, ws, ws_bytes, out_val, out_idx, out_nlse2, stream, false);
+  return qhead_fwd_impl(H_b, rows, E_out_b, b_out, n_items, d, mode, ws, ws_bytes, out_val, out_idx, out_nlse2, stream, 0);
 }
 // ARGMAX with 32 states per wave and at most 128 registers (d = 128): slower on its own than the 64-state form, but its
 // waves fit beside qfwd2_kernel's on a SIMD (that kernel leaves 136 of the 512 registers per lane and 127 KiB of LDS), so
@@ -857,11 +857,23 @@ extern "C" int cqlrec_qhead_fwd(const uint16_t* H_b, int64_t rows, const uint16_
 int cql_qhead_argmax_beside(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                             int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream) {
   return qhead_fwd_impl(H_b, rows, E_out_b, b_out, n_items, d, CQLREC_QHEAD_ARGMAX, ws, ws_bytes, out_val, out_idx, nullptr,
-                        (cqlrec_stream)stream, d == 128);
+                        (cqlrec_stream)stream, d == 128 ? 1 : 0);
+}
+// ARGMAX as the training step launches it, on the branch stream WHILE the fused forward of the other branch runs.  d = 128:
+// the two-waves-per-SIMD form of the skeleton -- one of its waves (<= 128 registers) fits beside a wave of qfwd2_kernel (368)
+// on a SIMD and its products run in that kernel's issue gaps, which is worth more to the step than the faster kernel:
+// qargmax2_kernel alone takes 0.077 instead of 0.087 ms, the step with it 0.702 instead of 0.689 ms (same box, 2 x A/B).
+// d = 256: nothing fits beside qfwd3_kernel anyway; qargmax2_kernel (1.59 instead of 2.02 ms; cfg5shard step -10 %).
+int cql_qhead_argmax_step(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                          int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream) {
+  static const int force2 = getenv("CQL_QARGMAX2") && getenv("CQL_QARGMAX2")[0] == '2';      // A/B: the new kernel in the step too
+  return qhead_fwd_impl(H_b, rows, E_out_b, b_out, n_items, d, CQLREC_QHEAD_ARGMAX, ws, ws_bytes, out_val, out_idx, nullptr,
+                        (cqlrec_stream)stream, (d == 128 && !force2) ? 2 : 0);
 }
 static int qhead_fwd_impl(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                          int32_t d, int32_t mode, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx,
-                         float* out_nlse2, cqlrec_stream stream, bool small_waves) {
+                         float* out_nlse2, cqlrec_stream stream, int form) {
+  const bool small_waves = form == 1;          // 0: the fastest form on its own; 1: small waves; 2: the skeleton's 64-state form
   CQL_REQUIRE(H_b && E_out_b && b_out && ws && out_val, "qhead_fwd: NULL pointer");
   CQL_REQUIRE(d == 64 || d == 128 || d == 256, "qhead_fwd: d=%d unsupported", d);
   CQL_REQUIRE(rows > 0 && n_items > 0, "qhead_fwd: rows=%lld n_items=%lld", (long long)rows, (long long)n_items);
@@ -894,6 +906,18 @@ static int qhead_fwd_impl(const uint16_t* H_b, int64_t rows, const uint16_t* E_o
     if (small_waves) {
       CqlProfScope prof(CQLREC_PH_QHEAD_ARGMAX, s);
       qs_launch_n<128, 1, QM_ARGMAX, QS_NBUF, 4>(a, sp.rblks, s);
+    } else if (form == 0 && cql_qargmax2_supported(d, n_items)) {
+      // one wave per SIMD, software-pipelined (qhead_argmax2.hip); fewer, longer slices than the generic form: the partials
+      // fit the workspace carved above (same [slice][row] layout, fewer slices)
+      int ns2;
+      int64_t sr2;
+      cql_qargmax2_split(rows, n_items, d, &ns2, &sr2);
+      CQL_REQUIRE(ns2 <= sp.nsplit || (int64_t)ns2 * rows * 4 <= seg, "qhead_fwd: argmax partials do not fit");
+      a.nsplit = ns2;
+      a.split_rows = sr2;
+      CqlProfScope prof(CQLREC_PH_QHEAD_ARGMAX, s);
+      const int rc = cql_qargmax2_run(H_b, rows, E_out_b, b_out, n_items, d, ns2, sr2, a.part_a, a.part_i, s);
+      if (rc != CQLREC_OK) return rc;
     } else {
       qs_launch(QM_ARGMAX, a, d, sp.rblks, s);
     }

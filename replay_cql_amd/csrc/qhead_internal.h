@@ -123,6 +123,9 @@ int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
 int cql_qhead_argmax_beside(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                             int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream);
 
+int cql_qhead_argmax_step(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
+                          int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream);
+
 // qhead_fwd2.hip: the fused forward (lse + softmax-weighted item sum) as a one-wave-per-SIMD kernel (d = 128)
 struct QFwd2Args {
   const uint16_t* H_b;      // [n_states x D] owner rows
@@ -139,6 +142,11 @@ struct QFwd2Args {
 };
 bool cql_qfwd2_supported(int d, int64_t n_items);
 int cql_qfwd2_run(const QFwd2Args& a, int d, hipStream_t s);
+// qhead_argmax2.hip: the ARGMAX pass as a one-wave-per-SIMD kernel (d = 128, 256); partials in QM_ARGMAX's format
+bool cql_qargmax2_supported(int d, int64_t n_items);
+void cql_qargmax2_split(int64_t rows, int64_t n_items, int d, int* nsplit, int64_t* split_rows);
+int cql_qargmax2_run(const uint16_t* H_b, int64_t rows, const uint16_t* E_b, const float* bias, int64_t n_items, int d,
+                     int nsplit, int64_t split_rows, float* part_v, int32_t* part_i, hipStream_t s);
 // qhead_fwd3.hip: the same pass for d = 256 (one 32-state group per wave, 128 states per block)
 bool cql_qfwd3_supported(int d, int64_t n_items);
 int cql_qfwd3_run(const QFwd2Args& a, int d, hipStream_t s);

@@ -476,7 +476,7 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
     CQL_TRY(cql_qhead_argmax_beside(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star,
                                     (hipStream_t)sb));
   else
-    CQL_TRY(cqlrec_qhead_fwd(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, CQLREC_QHEAD_ARGMAX, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star, nullptr, sb));
+    CQL_TRY(cql_qhead_argmax_step(w.hb + Bd, B, p.Eout_b, p.b_out, N, d, w.ws_q2, w.ws_q_bytes, w.maxv, w.a_star, (hipStream_t)sb));
   CQL_TRY(cqlrec_gather_dot(w.hb_t, p.tEout_b, p.tb_out, w.a_star, B, d, w.q_targ, sb));
   if (par && (hipEventRecord(ss.join2, ss.s2) != hipSuccess || hipStreamWaitEvent(s, ss.join2, 0) != hipSuccess)) {
     cql_set_error("train_step_forward: joining the forward branches failed");
