@@ -87,7 +87,7 @@ import torch  # noqa: E402
 
 CONFIGS = {
     # BASELINE.json configs[2] (the configuration the metric is quoted on) and configs[1]
-    "cfg3": dict(users=1_000_000, items=100_000, d=128, window=50, batch=4096, k=10, topk_users=65_536),
+    "cfg3": dict(users=1_000_000, items=100_000, d=128, window=50, batch=4096, k=10, topk_users=131_072),
     "cfg2": dict(users=100_000, items=10_000, d=64, window=50, batch=4096, k=10, topk_users=65_536),
     "tiny": dict(users=2_000, items=1_000, d=64, window=10, batch=256, k=10, topk_users=2_000),
     # BASELINE.json configs[0] shape (MovieLens-1M: 6 040 users, 3 883 items, ~836 K events -> long histories)
@@ -112,6 +112,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-topk", action="store_true")
+    ap.add_argument("--topk-chunk", type=int, default=None,
+                    help="users per launch of the top-K scoring kernel (default: the config's topk_users)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--dp-variant", default="auto", choices=["auto", "sharded", "allreduce"],
                     help="ranks > 1: row-sharded optimizer (reduce-scatter / own-row Adam / bf16 all-gather), replicated "
@@ -364,7 +366,7 @@ def main():
     if not args.no_topk:
         # all users of this rank's shard, in chunks of cfg["topk_users"] (one launch of the scoring kernel each)
         nu = hi - lo
-        tk_chunk = min(cfg["topk_users"], nu)
+        tk_chunk = min(args.topk_chunk or cfg["topk_users"], nu)
         users = torch.arange(nu, dtype=torch.int32, device=dev)
         # seen lists = items sorted inside each user's row (input preparation, untimed)
         rows = torch.repeat_interleave(torch.arange(hi - lo, device=dev), off[1:] - off[:-1])
@@ -404,7 +406,8 @@ def main():
             # `frac` = the PASS-level fraction (encode + seen bitmap + scoring/selection + merge, all users of the shard);
             # the scoring kernel's own launches are reported beside it
             pass_tf = 2.0 * nu * NI * d / (dtk / reps) / 1e12
-            topk["roofline"] = {"kernel": "qtopk2_kernel<128> (scores + on-chip top-k selection)" if fused
+            topk["roofline"] = {"kernel": ("qtopk4_kernel<128>" if tk_chunk >= 512 * 160 else "qtopk2_kernel<128>") +
+                                " (scores + on-chip top-k selection)" if fused
                                 else "qstream_kernel<TOPK> / <TILEMAX>", "bound": "mfma",
                                 "achieved": pass_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                 "frac": pass_tf / PEAK_BF16_MFMA_TFLOPS, "traffic": None,

@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libcqlrec.so"
 TORCH_LIB = PKG / "libcqlrec_torch.so"      # torch.ops.cqlrec.* registration shim over the C ABI (csrc/torch_ops.cpp)
-SOURCES = ["misc.hip", "qhead.hip", "qhead_de.hip", "qhead_de2.hip", "qhead_de3.hip", "qhead_argmax2.hip", "qhead_fwd2.hip", "qhead_fwd3.hip", "qhead_topk2.hip", "topk.hip", "gbwd.hip", "prep.hip", "train.hip"]
+SOURCES = ["misc.hip", "qhead.hip", "qhead_de.hip", "qhead_de2.hip", "qhead_de3.hip", "qhead_argmax2.hip", "qhead_fwd2.hip", "qhead_fwd3.hip", "qhead_topk2.hip", "qhead_topk4.hip", "topk.hip", "gbwd.hip", "prep.hip", "train.hip"]
 # misc.hip holds the Adam kernel whose expression order is normative: no fma contraction anywhere in that file
 EXTRA = {
     "misc.hip": ["-ffp-contract=off"],
@@ -26,6 +26,7 @@ EXTRA = {
     "qhead_de3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "qhead_argmax2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "qhead_topk2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "qhead_topk4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "qhead_fwd2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "qhead_fwd3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],

@@ -119,6 +119,10 @@ int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand);
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
                         int64_t n_cand, uint32_t* bits, hipStream_t s, int beside_scoring = 0);
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
+// qhead_topk4.hip: the same pass with four user groups per wave (512 users per block); chosen by shape inside
+// cql_topk2_split / cql_topk2_run, so the callers of those two need not know
+bool cql_topk4_use(int d, int k, int64_t n_users, int64_t n_cand);
+int cql_topk4_run(const QTk2Args& a, hipStream_t s);
 
 int cql_qhead_argmax_beside(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                             int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream);

@@ -525,7 +525,8 @@ bool cql_topk2_supported(int d, int k, int64_t n_cand) {
 
 // item slices: one block per CU when the users alone do not fill the chip
 void cql_topk2_split(int64_t n_users, int64_t n_cand, int* nsplit, int64_t* split_rows) {
-  const int64_t rblks = (n_users + 255) / 256;
+  const int upb = cql_topk4_use(128, 1, n_users, n_cand) ? 512 : 256;      // users per block (qtopk4_kernel / qtopk2_kernel)
+  const int64_t rblks = (n_users + upb - 1) / upb;
   const int64_t stages = (n_cand + 63) / 64;
   int64_t want = (tk2_cus() + rblks - 1) / rblks;
   static const char* env = getenv("CQL_TOPK2_NSPLIT");
@@ -556,6 +557,7 @@ int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, cons
 
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s) {
   if (!cql_topk2_supported(d, a.k, a.n_cand)) return CQLREC_ERR_INVALID;
+  if (cql_topk4_use(d, a.k, a.n_users, a.n_cand)) return cql_topk4_run(a, s);
   constexpr int smem = Tk2Cfg<128>::SMEM;
   static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
   bool& attr_set = attr_set_dev[cql_device_slot()];
