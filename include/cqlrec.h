@@ -379,9 +379,10 @@ int cqlrec_prof_read(double* ms_sum /* [host] CQLREC_PH_COUNT */, int64_t* launc
 
 /* Schedule marks (tools/phase_timing.py): nine timing events at the joints of the middle step of a
  * cqlrec_train_steps call (n_steps >= 4) -- loss, dH done, item-side backward done, encoder+gather backward done,
- * Adam(E_in) done, Adam(E_out) done, next step's prologue done, its LSE done, its loss -- cheap enough not to disturb
+ * Adam(E_in) done, Adam(E_out) done, next step's prologue done, its LSE done, its loss; then encoder dx done, window-
+ * gather backward done, the next step's sample + pair sorts done -- cheap enough not to disturb
  * the overlap they measure.  marks_read synchronises and returns ms relative to the first mark (-1: not recorded). */
-#define CQLREC_DEBUG_MARKS 9
+#define CQLREC_DEBUG_MARKS 12
 int cqlrec_debug_marks_enable(int32_t on);
 int cqlrec_debug_marks_read(float* ms_out /* [host] CQLREC_DEBUG_MARKS */);
 

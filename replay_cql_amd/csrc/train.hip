@@ -9,7 +9,7 @@ static int g_concurrency = -1;   // -1: read CQL_CONCURRENCY on first use (defau
 
 // ---- schedule marks (tools/phase_timing.py): a handful of timing events at the joints of ONE step of a
 // cqlrec_train_steps call -- cheap enough not to disturb the overlap they measure (unlike bracketing every kernel)
-enum { MK_LOSS = 0, MK_DH, MK_DE, MK_CHAIN, MK_ADAM_IN, MK_ADAM_OUT, MK_PROLOGUE, MK_LSE, MK_NEXT_LOSS, MK_COUNT };
+enum { MK_LOSS = 0, MK_DH, MK_DE, MK_CHAIN, MK_ADAM_IN, MK_ADAM_OUT, MK_PROLOGUE, MK_LSE, MK_NEXT_LOSS, MK_ENC_DX, MK_GATHER_BWD, MK_SORT_NEXT, MK_COUNT };
 static hipEvent_t g_marks[MK_COUNT];
 static int g_marks_on = 0;       // cqlrec_debug_marks_enable
 static int g_mark_phase = 0;     // 1: backward of the marked step, 2: forward of the step after it
@@ -577,8 +577,10 @@ int backward_chain_impl(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream 
                                   c->grads + L.off_b1, c->grads + L.off_W2, c->grads + L.off_b2, w.dh0, 2, ss.s2));
     CQL_HIP_TRY(hipEventRecord(ss.join2, ss.s2), "train_step_backward_rest");
   }
+  if (g_mark_phase == 1) mark(MK_ENC_DX, s);
   if (ss.ok) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.sorted[step & 1], 0), "train_step_backward_rest");
   CQL_TRY(cqlrec_gather_pool_bwd_apply(w.dh0, B, W, d, N, w.ws_gb, w.ws_gb_bytes, c->grads + L.off_E_in, stream));
+  if (g_mark_phase == 1) mark(MK_GATHER_BWD, s);
   if (split) CQL_HIP_TRY(hipStreamWaitEvent(s, ss.join2, 0), "train_step_backward_rest");
   return CQLREC_OK;
 }
@@ -672,6 +674,7 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
         // the pairs its backward will need (two radix sorts, ~35 small launches) behind that
         CQL_TRY(sample_ahead(c, step + 1, (cqlrec_stream)ss.s3, ss.presample));
         CQL_HIP_TRY(hipEventRecord(ss.sorted[(step + 1) & 1], ss.s3), "train_steps");
+        if (g_mark_phase == 1) mark(MK_SORT_NEXT, ss.s3);
         sampled = ss.presample;
       }
       CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.loss, 0), "train_steps");

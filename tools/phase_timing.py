@@ -80,10 +80,11 @@ def main():
     N.check(lib.cqlrec_debug_marks_enable(1))
     core.train_steps(64)
     torch.cuda.synchronize()
-    ms = (C.c_float * 9)()
+    ms = (C.c_float * 12)()
     N.check(lib.cqlrec_debug_marks_read(ms))
     N.check(lib.cqlrec_debug_marks_enable(0))
-    names = ("loss", "dH", "dE_out", "enc+gather bwd", "adam E_in", "adam E_out", "next prologue", "next LSE", "next loss")
+    names = ("loss", "dH", "dE_out", "enc+gather bwd", "adam E_in", "adam E_out", "next prologue", "next LSE", "next loss", "enc dx", "gather bwd",
+             "next sample+sort")
     print("schedule marks of one pipelined step (us after the loss): " +
           "  ".join(f"{n}={1e3 * ms[i]:.0f}" for i, n in enumerate(names)), flush=True)
     for conc in (1, 0):
