@@ -279,6 +279,15 @@ int cqlrec_train_step_forward(const cqlrec_train_ctx* ctx /* [host] */, uint64_t
  * the item-side half of step t are still running on its side stream. */
 int cqlrec_train_step_forward_after(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,
                                     cqlrec_stream stream, void* items_ready /* hipEvent_t */);
+/* forward_after that ALSO starts the long part of backward_items -- the dE_out kernel, which needs nothing from the
+ * loss but the forward's logsumexp -- on `items_stream` as soon as the catalogue pass of branch A is done, i.e. under
+ * the arg-max pass, the TD target and the loss (what cqlrec_train_steps does for a single rank).  The
+ * cqlrec_train_step_backward_items call of the same step, which must then be made on `items_stream`, adds only the
+ * parts that need the loss (one-hot rows, then the cut pieces: the order in which a gradient row is summed does not
+ * change).  items_ready may be NULL. */
+int cqlrec_train_step_forward_early_items(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, float* loss_out,
+                                          cqlrec_stream stream, void* items_ready /* hipEvent_t */,
+                                          cqlrec_stream items_stream);
 int cqlrec_train_step_backward_items(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
 int cqlrec_train_step_backward_rest(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, cqlrec_stream stream);
 int cqlrec_train_step_update_range(const cqlrec_train_ctx* ctx /* [host] */, uint64_t step, int64_t lo, int64_t hi,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "cqlrec_train_step_update": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_forward": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),
     "cqlrec_train_step_forward_after": (i32, [C.POINTER(TrainCtx), u64, vp, vp, vp]),
+    "cqlrec_train_step_forward_early_items": (i32, [C.POINTER(TrainCtx), u64, vp, vp, vp, vp]),
     "cqlrec_train_step_backward_items": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_backward_rest": (i32, [C.POINTER(TrainCtx), u64, vp]),
     "cqlrec_train_step_update_range": (i32, [C.POINTER(TrainCtx), u64, i64, i64, vp]),

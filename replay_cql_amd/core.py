@@ -243,13 +243,15 @@ class CQLCore:
         side = self._side
         ev_fwd, ev_rest, ev_items = self._ev
         pending = False
+        self._early_de = os.environ.get("CQL_EARLY_DE", "1") != "0"
         for i in range(n_steps):
             lo = None if losses is None else losses[i:i + 1]
-            if pending:
-                N.check(self.lib.cqlrec_train_step_forward_after(C.byref(c), self.step, _ptr(lo), s, ev_items.cuda_event),
-                        "train_step_forward_after")
-            else:
-                N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(lo), s), "train_step_forward")
+            # the long dE_out kernel of this step is started by the forward itself, on the side stream, as soon as the
+            # fused forward has produced the logsumexp -- under the arg-max pass and the loss; backward_items below adds
+            # the parts that need the loss (CQL_EARLY_DE=0: all of it behind the loss)
+            N.check(self.lib.cqlrec_train_step_forward_early_items(
+                C.byref(c), self.step, _ptr(lo), s, ev_items.cuda_event if pending else None,
+                side.cuda_stream if self._early_de else None), "train_step_forward_early_items")
             ev_fwd.record(main)
             N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
             ev_rest.record(main)
@@ -344,13 +346,13 @@ class CQLCore:
                 N.check(self.lib.cqlrec_train_step_update_range(C.byref(c), self.step, lo, hi, stream), "update_range")
 
         pending = False
+        early_de = os.environ.get("CQL_EARLY_DE", "1") != "0"
         for i in range(n_steps):
             lo_ = None if losses is None else losses[i:i + 1]
-            if pending:
-                N.check(self.lib.cqlrec_train_step_forward_after(C.byref(c), self.step, _ptr(lo_), s, ev_items.cuda_event),
-                        "train_step_forward_after")
-            else:
-                N.check(self.lib.cqlrec_train_step_forward(C.byref(c), self.step, _ptr(lo_), s), "train_step_forward")
+            # (as in train_steps: the long dE_out kernel starts under the arg-max pass and the loss)
+            N.check(self.lib.cqlrec_train_step_forward_early_items(
+                C.byref(c), self.step, _ptr(lo_), s, ev_items.cuda_event if pending else None,
+                side.cuda_stream if early_de else None), "train_step_forward_early_items")
             ev_fwd.record(main)
             N.check(self.lib.cqlrec_train_step_backward_rest(C.byref(c), self.step, s), "train_step_backward_rest")
             ev_rest.record(main)

@@ -604,10 +604,34 @@ extern "C" int cqlrec_train_step_forward_after(const cqlrec_train_ctx* c, uint64
   return forward_impl(c, step, loss_out, stream, (hipEvent_t)items_ready);
 }
 
+// phase 1 + the long kernel of phase 2 (see the header).  The cut pieces of that kernel wait, by step parity, for the
+// backward_items call of the same step.
+static CqlAdamFix g_early_fix[2];
+static bool g_early_long[2] = {false, false};
+extern "C" int cqlrec_train_step_forward_early_items(const cqlrec_train_ctx* c, uint64_t step, float* loss_out,
+                                                     cqlrec_stream stream, void* items_ready, cqlrec_stream items_stream) {
+  CQL_TRY(check_ctx(c));
+  SideStream& ss = side_stream();
+  const bool early = items_stream && items_stream != stream && need_side_streams(ss) && ss.ok && !onehot_atomic();
+  g_early_long[step & 1] = false;
+  if (!early) return forward_impl(c, step, loss_out, stream, (hipEvent_t)items_ready);
+  g_early_fix[step & 1] = CqlAdamFix{};
+  CQL_TRY(forward_impl(c, step, loss_out, stream, (hipEvent_t)items_ready, nullptr, (hipStream_t)items_stream,
+                       &g_early_fix[step & 1]));
+  g_early_long[step & 1] = true;
+  return CQLREC_OK;
+}
+
 // phase 2: the catalogue-side gradients g_E_out, g_b_out (half of the gradient bytes; a data-parallel caller starts
 // their all-reduce while phase 3 runs)
 extern "C" int cqlrec_train_step_backward_items(const cqlrec_train_ctx* c, uint64_t step, cqlrec_stream stream) {
   CQL_TRY(check_ctx(c));
+  if (g_early_long[step & 1]) {      // the long kernel is running (or done) on this stream: one-hot rows, then the cut pieces
+    g_early_long[step & 1] = false;
+    const cqlrec_layout& L = c->layout;
+    CQL_TRY(backward_items_onehot_impl(c, step, stream));
+    return cql_qde_fixup_deferred(g_early_fix[step & 1], c->grads + L.off_E_out, c->grads + L.off_b_out, (hipStream_t)stream);
+  }
   return backward_items_impl(c, step, stream);
 }
 
