@@ -22,5 +22,7 @@ echo "[r03] PMC passes, d = 128 (cfg3 shape)"
 tools/pmc_passes.sh $out/pmc128 "--modes argmax,fused,bwd --reps 5" sq1 sq2 fetch write > $out/pmc_qhead_d128.txt 2>&1 || { tail -5 $out/pmc_qhead_d128.txt; exit 1; }
 echo "[r03] PMC passes, d = 256 (cfg5 per-GPU shape)"
 tools/pmc_passes.sh $out/pmc256 "--items 1000000 --d 256 --modes argmax,fused,bwd --reps 2" sq1 sq2 fetch write > $out/pmc_qhead_d256.txt 2>&1 || { tail -5 $out/pmc_qhead_d256.txt; exit 1; }
-rm -rf $out/pmc128 $out/pmc256
+echo "[r03] PMC passes, top-K scoring kernel (131 072 users x 100 000 items, qtopk4_kernel)"
+tools/pmc_passes.sh $out/pmctk "--modes topk --topk-users 131072 --reps 3" sq1 sq2 > $out/pmc_topk.txt 2>&1 || { tail -5 $out/pmc_topk.txt; exit 1; }
+rm -rf $out/pmc128 $out/pmc256 $out/pmctk
 echo "[r03] done"
