@@ -8,5 +8,5 @@ df = pd.concat(frames)
 df["k"] = df["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
 piv = df.pivot_table(index="k", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
 pd.set_option("display.width", 250, "display.max_columns", 50, "display.float_format", lambda x: f"{x:,.0f}")
-keep = piv.index.str.contains("qstream|qde|qfwd|topk|adam|gather_pool|segsum")
+keep = piv.index.str.contains("qstream|qde|qfwd|qargmax|topk|adam|gather_pool|segsum")
 print(piv[keep].to_string())
