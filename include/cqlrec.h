@@ -224,6 +224,13 @@ int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, const uint16_t
                             const int32_t* seen_rows, int32_t k, void* ws, int64_t ws_bytes, int32_t* out_idx,
                             float* out_val, int32_t* out_cnt, int32_t phase, cqlrec_stream stream);
 
+/* Debug / tests: which form of the seen filter the last SEEN (or ALL) phase on `ws` left for the on-chip-selection
+ * kernel.  *out (host) = -1: this shape filters by bitmap only; 0: entry lists (256-byte slots per 128 users x 64 items
+ * + an overflow area, built in the bitmap's space; the bitmap was not built); 1: the lists did not fit, bitmap.
+ * Synchronises `stream`. */
+int cqlrec_topk_seen_form(const void* ws, int64_t n_users, int64_t n_cand, int32_t d, int32_t k, int32_t* out,
+                          cqlrec_stream stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * a8  Whole training step = TorchRecommender._run_train_step (replay/models/base_torch_rec.py:32-39) without
  * the per-step host sync.  The step is split in two so that a data-parallel caller can all-reduce ctx.grads

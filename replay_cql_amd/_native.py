@@ -93,6 +93,7 @@ SIGNATURES = {
     "cqlrec_cast_bf16": (i32, [vp, vp, i64, vp]),
     "cqlrec_topk_ws_bytes": (i64, [i64, i64, i32, i32]),
     "cqlrec_score_topk": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, vp]),
+    "cqlrec_topk_seen_form": (i32, [vp, i64, i64, i32, i32, C.POINTER(C.c_int32), vp]),
     "cqlrec_score_topk_phase": (i32, [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, vp, vp, vp, i32, vp]),
     "cqlrec_train_ws_bytes": (i64, [i32, i64, i32, i32]),
     "cqlrec_train_step_fwd_bwd": (i32, [C.POINTER(TrainCtx), u64, vp, vp]),

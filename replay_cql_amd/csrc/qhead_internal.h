@@ -112,10 +112,17 @@ struct QTk2Args {
   const uint32_t* seen_bits;    // cql_topk2_seen_bits layout, or NULL (no filter)
   unsigned long long* keys;     // [nsplit][n_users][2][QS_TOPK_K]
   int k;
+  // qtopk4_kernel only: the seen filter as entry lists (cql_topk2_seen_bits builds them IN the bitmap's space when the
+  // shape takes that kernel; the bitmap itself only when they do not fit) and the word that picks between the two forms
+  const uint32_t* seen_lists;        // [ceil(n_users / 128)][stages][64 words] slots, or NULL
+  const uint16_t* seen_lists_ovf;    // overflow entries
+  const uint32_t* guard;             // NULL: run; else run iff (*guard != 0) == (guard_want != 0)
+  int guard_want;
 };
 bool cql_topk2_supported(int d, int k, int64_t n_cand);
 void cql_topk2_split(int64_t n_users, int64_t n_cand, int* nsplit, int64_t* split_rows);
 int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand);
+const uint32_t* cql_topk2_lists_word(const uint32_t* bits, int64_t n_users, int64_t n_cand);    // NULL: bitmap only
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
                         int64_t n_cand, uint32_t* bits, hipStream_t s, int beside_scoring = 0);
 int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
@@ -123,6 +130,10 @@ int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s);
 // cql_topk2_split / cql_topk2_run, so the callers of those two need not know
 bool cql_topk4_use(int d, int k, int64_t n_users, int64_t n_cand);
 int cql_topk4_run(const QTk2Args& a, hipStream_t s);
+bool cql_topk4_lists_on();
+bool cql_topk4_lists_fit(int64_t n_users, int64_t n_cand, int64_t space_bytes);
+int cql_topk4_seen_lists(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
+                         int64_t n_cand, void* space, int64_t space_bytes, uint32_t* flag, hipStream_t s);
 
 int cql_qhead_argmax_beside(const uint16_t* H_b, int64_t rows, const uint16_t* E_out_b, const float* b_out, int64_t n_items,
                             int32_t d, void* ws, int64_t ws_bytes, float* out_val, int32_t* out_idx, hipStream_t stream);

@@ -465,7 +465,9 @@ template <int TK2_BCH>
 __global__ __launch_bounds__(256) void topk2_seen_bits_kernel(const int64_t* __restrict__ seen_off,
                                                               const int32_t* __restrict__ seen_items,
                                                               const int32_t* __restrict__ seen_rows, int64_t n_users,
-                                                              int64_t n_cand, int64_t nst_all, uint32_t* __restrict__ bits) {
+                                                              int64_t n_cand, int64_t nst_all, uint32_t* __restrict__ bits,
+                                                              const uint32_t* __restrict__ only_if) {
+  if (only_if != nullptr && *only_if == 0u) return;       // the entry lists hold everything (qhead_topk4.hip): no bitmap
   __shared__ __attribute__((aligned(16))) uint32_t tile[TK2_BCH * 128];     // [stage][user][2 words]
   const int t = threadIdx.x, user = t >> 2, q = t & 3;
   const int64_t u = (int64_t)blockIdx.x * 64 + user;
@@ -539,18 +541,38 @@ void cql_topk2_split(int64_t n_users, int64_t n_cand, int* nsplit, int64_t* spli
   *nsplit = (int)((n_cand + *split_rows - 1) / *split_rows);
 }
 
+static int64_t tk2_dense_bytes(int64_t n_users, int64_t n_cand) {
+  return (((n_users + 63) / 64) * ((n_cand + 63) / 64) * 512 + 255) / 256 * 256;
+}
+static bool tk2_lists(int64_t n_users, int64_t n_cand) {
+  return cql_topk4_lists_on() && cql_topk4_use(128, 1, n_users, n_cand) &&
+         cql_topk4_lists_fit(n_users, n_cand, tk2_dense_bytes(n_users, n_cand));
+}
+// the bitmap -- whose space the entry lists of qtopk4_kernel are built in -- and the word that says which of the two it holds
 int64_t cql_topk2_bits_bytes(int64_t n_users, int64_t n_cand) {
-  return ((n_users + 63) / 64) * ((n_cand + 63) / 64) * 512;
+  return tk2_dense_bytes(n_users, n_cand) + (tk2_lists(n_users, n_cand) ? 256 : 0);
+}
+const uint32_t* cql_topk2_lists_word(const uint32_t* bits, int64_t n_users, int64_t n_cand) {
+  if (!bits || !tk2_lists(n_users, n_cand)) return nullptr;
+  return bits + tk2_dense_bytes(n_users, n_cand) / 4;
 }
 
 int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
                         int64_t n_cand, uint32_t* bits, hipStream_t s, int beside_scoring) {
+  // where the scoring kernel takes entry lists: those first, in the bitmap's space; the bitmap then only if they did not fit
+  const uint32_t* only_if = nullptr;
+  if (uint32_t* word = const_cast<uint32_t*>(cql_topk2_lists_word(bits, n_users, n_cand))) {
+    const int rc = cql_topk4_seen_lists(seen_off, seen_items, seen_rows, n_users, n_cand, bits, tk2_dense_bytes(n_users, n_cand),
+                                        word, s);
+    if (rc != CQLREC_OK) return rc;
+    only_if = word;
+  }
   if (beside_scoring)
     hipLaunchKernelGGL(topk2_seen_bits_kernel<12>, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off,
-                       seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits);
+                       seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits, only_if);
   else
     hipLaunchKernelGGL(topk2_seen_bits_kernel<96>, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off,
-                       seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits);
+                       seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits, only_if);
   CQL_LAUNCH_CHECK("topk2_seen_bits");
   return CQLREC_OK;
 }

@@ -24,11 +24,15 @@
 #define TK4_Q 12         // queue entries per lane and group (16 queues of 6 KiB per block beside the 61 KiB ring)
 #define TK4_K 16
 #define TK4_NBUF 3
+#define TK4_SLOT_WORDS 64
+#define TK4_SLOT_CAP 124       // 256 bytes = 2 header words + 124 16-bit entries (lanes 2..63 of the wave hold two each)
 static_assert(TK4_K == QS_TOPK_K, "list format shared with topk_merge_kernel");
 
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_4;
 typedef __attribute__((address_space(3))) u32x2_4 lds_u2_4;
+typedef __attribute__((address_space(3))) unsigned int lds_u32_4;
+typedef __attribute__((address_space(3))) u32x4 lds_u4_4;
 
 template <int D>
 struct Tk4Cfg {
@@ -38,7 +42,8 @@ struct Tk4Cfg {
   static constexpr int BUF = C::STAGE_BYTES + STRIP + SEEN;
   static constexpr int RING = TK4_NBUF * BUF;
   static constexpr int QUEUES = 4 * TK4_G * TK4_Q * 512;
-  static constexpr int SMEM = RING + QUEUES;
+  static constexpr int LISTS = TK4_NBUF * 4 * 256;      // LISTS form: 256 B (128 entries) per wave and ring buffer
+  static constexpr int SMEM = RING + QUEUES + LISTS;
 };
 
 #define TK4_AW(dst, src) asm("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(src))
@@ -66,8 +71,13 @@ __device__ __forceinline__ void tk4_mfma_acc(f32x16& acc, const bf16x8& a_frag, 
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "a"(b_acc));
 }
 
-template <int D>
+// LISTS: the seen filter arrives as entry lists (tk4_lists_* below: one 256-byte slot per wave of 128 users and stage of
+// 64 items, longer lists continue in an overflow area) instead of the dense bitmap; the wave expands the list of a
+// stage into the same 1 KiB of mask words in LDS that the dense form streams in.
+template <int D, bool LISTS>
 __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
+  // the two forms are launched one behind the other; the word the list builder leaves picks one on the device
+  if (a.guard != nullptr && ((*a.guard != 0u) != (a.guard_want != 0))) return;
   using T = Tk4Cfg<D>;
   using C = typename T::C;
   constexpr int KS = C::KS;
@@ -105,20 +115,23 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
   // seen words of this wave's 128 users = two consecutive 64-user blocks of the bitmap ([block][stage][64 users][2 words]):
   // lanes 0..31 fetch the first block's 512 B of a stage, lanes 32..63 the second block's.  A block past n_users does not
   // exist in the bitmap: its lanes get an offset past num_records (they read 0).  No filter = an empty buffer.
+  // LISTS: this wave's row of 256-byte slots ([wave of 128 users][stage]: count, overflow offset, 124 entries).
   const int64_t nst_all = (a.n_cand + C::TI - 1) / C::TI;
-  const int64_t nblk64 = (a.n_users + 63) / 64;
-  const int64_t blk0 = res0 >> 6;
-  const bool has_seen = a.seen_bits != nullptr && blk0 < nblk64;          // wave-uniform
-  const uint32_t* wsrc = has_seen ? a.seen_bits + blk0 * nst_all * 128 : (const uint32_t*)a.bias;
-  const bool two_blocks = has_seen && (blk0 + 1 < nblk64);
-  const int64_t w_records = has_seen ? (two_blocks ? 2 : 1) * nst_all * 512 : 0;     // < 2^31: checked by the host
+  const int64_t nblk64 = LISTS ? (a.n_users + 127) / 128 : (a.n_users + 63) / 64;
+  const int64_t blk0 = LISTS ? (res0 >> 7) : (res0 >> 6);
+  const uint32_t* const seen_src = LISTS ? a.seen_lists : a.seen_bits;
+  const bool has_seen = seen_src != nullptr && blk0 < nblk64;          // wave-uniform
+  const uint32_t* wsrc = has_seen ? seen_src + blk0 * nst_all * (LISTS ? 64 : 128) : (const uint32_t*)a.bias;
+  const bool two_blocks = !LISTS && has_seen && (blk0 + 1 < nblk64);
+  const int64_t w_records = has_seen ? (LISTS ? nst_all * 256 : (two_blocks ? 2 : 1) * nst_all * 512) : 0;   // < 2^31: host
   // (wave-uniform by construction; made so for the compiler too, which otherwise hands the asm a VGPR tuple)
   const uint64_t wp = (uint64_t)wsrc;
   const uint64_t wp_u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wp >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wp);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wp_u, 0, __builtin_amdgcn_readfirstlane((int)w_records),
                                                                   0x00020000);
-  const uint32_t voff_w = (uint32_t)((lane >> 5) * (uint32_t)(nst_all * 512) + (lane & 31) * 16);
+  const uint32_t voff_w = LISTS ? (uint32_t)lane * 4u
+                                : (uint32_t)((lane >> 5) * (uint32_t)(nst_all * 512) + (lane & 31) * 16);
   uint32_t voff;
   {
     const int sub = lane >> 5, r7 = (lane >> 2) & 7, slot = lane & 3;
@@ -133,7 +146,11 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
     const uint32_t bufp = __builtin_amdgcn_readfirstlane(smem_base + buf * T::BUF);
     const uint32_t gs = gstage0 + (uint32_t)stage;
     if (pc < C::LPS) bdma16(voff, rs_e, gs * C::STAGE_BYTES + C::PSTEP * pc, bufp + (4 * pc + wave) * 1024);
-    else if (pc == C::LPS) bdma16(voff_w, rs_w, gs * 512, bufp + C::STAGE_BYTES + T::STRIP + wave * 1024);
+    else if (pc == C::LPS) {
+      if constexpr (LISTS)
+        bdma4(voff_w, rs_w, gs * 256, __builtin_amdgcn_readfirstlane(smem_base + T::RING + T::QUEUES + (buf * 4 + wave) * 256));
+      else bdma16(voff_w, rs_w, gs * 512, bufp + C::STAGE_BYTES + T::STRIP + wave * 1024);
+    }
     else if (wave == (stage & 3)) bdma4(voff4, rs_b, gs * (C::TI * 4), bufp + C::STAGE_BYTES);
   };
 
@@ -319,6 +336,37 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
     refill = st + TK4_NBUF < nstage;
   };
 
+  // LISTS: the stage's slot (this wave's 256 staging bytes: word 0 = entries of the list, word 1 = where its part beyond
+  // TK4_SLOT_CAP continues in the overflow area, then the 16-bit entries (user in wave) << 6 | item in stage) becomes the
+  // stage's mask words -- clear them, set the bits -- in the gaps of the stage's first chain, one small step per gap
+  // (the wave's LDS operations execute in order: no wait between the steps beyond the one for the entries).
+  uint32_t ls_n = 0u, ls_e2 = 0u;
+  auto lists_step = [&](int gp) __attribute__((always_inline)) {
+    lds_u8* const mW = (lds_u8*)smem + boff_c + C::STAGE_BYTES + T::STRIP + wave * 1024;
+    const lds_u8* const stg = (const lds_u8*)smem + T::RING + T::QUEUES + (buf_c * 4 + wave) * 256;
+    auto set_bit = [&](uint32_t code) __attribute__((always_inline)) {
+      __hip_atomic_fetch_or((lds_u32_4*)(mW + (code >> 6) * 8 + ((code >> 5) & 1u) * 4), 1u << (code & 31u),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    if (gp == 0) {
+      ls_n = has_seen ? *(const lds_u32_4*)(stg) : 0u;
+      ls_e2 = *(const lds_u32_4*)(stg + 4 * lane);
+    } else if (gp == 1) {
+      *(lds_u4_4*)(mW + 16 * lane) = u32x4{0u, 0u, 0u, 0u};
+      ls_n = ls_n < 8192u ? ls_n : 8192u;     // (128 users x 64 items: no list is longer; bounds the loop below whatever was read)
+    } else if (gp == 2 || gp == 3) {
+      const uint32_t n_slot = ls_n < (uint32_t)TK4_SLOT_CAP ? ls_n : (uint32_t)TK4_SLOT_CAP;
+      const uint32_t idx = 2u * (uint32_t)lane - 4u + (uint32_t)(gp - 2);     // lanes 0, 1 hold the header
+      if (lane >= 2 && idx < n_slot) set_bit((ls_e2 >> (16 * (gp - 2))) & 0xFFFFu);
+    } else if (gp == 4) {
+      if (__builtin_expect(ls_n > (uint32_t)TK4_SLOT_CAP, 0)) {      // a stage of popular items: the rest, from global memory
+        const uint32_t ovf0 = *(const lds_u32_4*)(stg + 4);
+        const uint32_t n_ovf = __builtin_amdgcn_readfirstlane((int)(ls_n - (uint32_t)TK4_SLOT_CAP));
+        for (uint32_t i = (uint32_t)lane; i < n_ovf; i += 64u) set_bit((uint32_t)a.seen_lists_ovf[(uint64_t)ovf0 + i]);
+      }
+    }
+  };
+
   using G0 = std::integral_constant<int, 0>;
   using G1 = std::integral_constant<int, 1>;
   using G2 = std::integral_constant<int, 2>;
@@ -339,6 +387,10 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
       TK4_FENCE();
       next_read(IT, s);
       TK4_FENCE();
+      if constexpr (LISTS && !END) {
+        if (s < 5) lists_step(s);
+        TK4_FENCE();
+      }
     }
     if constexpr (!END) {      // the new stage's seen words (group 3's pending one of the old stage has just been used)
 #pragma unroll
@@ -433,6 +485,118 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
   }
 }
 
+// ---- the seen filter as entry lists ------------------------------------------------------------------------------------
+// A dense bitmap of 131 072 users x 100 000 items is 1.64 GB written per launch of the scoring kernel (0.25-0.45 ms at the
+// HBM write rate) to say ~9 M things.  Here: one 256-byte slot per (wave of 128 users, stage of 64 items) -- word 0 the
+// number of entries, word 1 where the list continues, then up to 124 16-bit entries (user in wave) << 6 | item in stage
+// -- and an overflow area for the longer lists (the stages of the most popular items: on a Zipf log nearly every user
+// has seen them).  Built in the bitmap's own space by six small launches + one scan; if the overflow area is too small
+// (users who have seen a large part of the catalogue) the word behind the space is set, the bitmap is built over it
+// after all and the scoring kernel of that form runs: both forms are always enqueued, the word picks on the device.
+struct Tk4Lists {
+  uint32_t* slots;      // [rows][stages][64]
+  uint16_t* ovf;        // [rows][row_cap]
+  int64_t rows, row_cap;
+};
+static Tk4Lists tk4_lists_carve(void* base, int64_t space_bytes, int64_t n_users, int64_t n_cand) {
+  Tk4Lists L;
+  L.rows = (n_users + 127) / 128;
+  const int64_t slot_bytes = L.rows * ((n_cand + 63) / 64) * (TK4_SLOT_WORDS * 4);
+  L.slots = (uint32_t*)base;
+  L.ovf = (uint16_t*)((char*)base + slot_bytes);
+  int64_t cap = (space_bytes - slot_bytes) / 2 / (L.rows > 0 ? L.rows : 1);
+  if (cap * L.rows > 0xFFFFFFFFll) cap = 0xFFFFFFFFll / L.rows;       // an offset is a 32-bit word of the slot header
+  L.row_cap = cap > 0 ? cap / 8 * 8 : 0;
+  return L;
+}
+// One block per row (128 users), modelled on topk2_seen_bits_kernel: the users' seen lists are ascending, so two
+// threads per user walk them once per chunk of TK4_LCH stages; the chunk's slots are assembled in LDS (counts by LDS
+// atomics, then the entries) and leave with one coalesced write each -- only the 64-byte parts a list reaches.  The part
+// of a list beyond TK4_SLOT_CAP goes to the row's overflow area, in stage order (header word 1 = where).
+#define TK4_LCH 96
+__global__ __launch_bounds__(256) void tk4_lists_kernel(const int64_t* __restrict__ seen_off,
+                                                        const int32_t* __restrict__ seen_items,
+                                                        const int32_t* __restrict__ seen_rows, int64_t n_users,
+                                                        int64_t n_cand, int64_t nst_all, uint32_t* __restrict__ slots,
+                                                        uint16_t* __restrict__ ovf, int64_t row_cap, uint32_t* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) uint32_t tile[TK4_LCH * TK4_SLOT_WORDS];     // the chunk's slots
+  __shared__ uint32_t fillpos[TK4_LCH], ovbase[TK4_LCH];
+  __shared__ uint32_t s_run, s_lost;
+  const int t = threadIdx.x, user = t >> 1, q = t & 1;
+  const int64_t u = (int64_t)blockIdx.x * 128 + user;
+  int64_t cur = 0, end = 0;                 // this user's entries not yet placed (kept in step by its two threads)
+  if (u < n_users) {
+    const int64_t srow = seen_rows ? (int64_t)seen_rows[u] : u;
+    cur = seen_off[srow];
+    end = seen_off[srow + 1];
+  }
+  if (t == 0) { s_run = 0u; s_lost = 0u; }
+  uint32_t* const dst = slots + (int64_t)blockIdx.x * nst_all * TK4_SLOT_WORDS;
+  const uint64_t row_base = (uint64_t)blockIdx.x * (uint64_t)row_cap;
+  const uint32_t ucode = (uint32_t)user << 6;
+  for (int64_t st0 = 0; st0 < nst_all; st0 += TK4_LCH) {
+    const int nst = (int)((nst_all - st0 < TK4_LCH) ? (nst_all - st0) : TK4_LCH);
+    for (int i = t; i < nst; i += 256) { tile[i * TK4_SLOT_WORDS] = 0u; fillpos[i] = 0u; }
+    __syncthreads();
+    const int64_t item_lo = st0 * 64, item_hi = (st0 + nst) * 64;
+    // ---- count
+    int64_t j = cur + q;
+    for (; j < end; j += 2) {
+      const int32_t id = seen_items[j];
+      if (id >= item_hi) break;
+      if (id >= item_lo && id < n_cand) atomicAdd(&tile[(int)((id >> 6) - st0) * TK4_SLOT_WORDS], 1u);
+    }
+    __syncthreads();
+    // ---- where the long lists continue: exclusive prefix of the excess over the chunk's stages (one thread: <= 96 terms)
+    if (t == 0) {
+      uint32_t run = s_run;
+      for (int i = 0; i < nst; ++i) {
+        const uint32_t n = tile[i * TK4_SLOT_WORDS];
+        ovbase[i] = run;
+        tile[i * TK4_SLOT_WORDS + 1] = (uint32_t)(row_base + run);
+        run += n > TK4_SLOT_CAP ? n - TK4_SLOT_CAP : 0u;
+      }
+      s_run = run;
+    }
+    __syncthreads();
+    // ---- place the entries (the same walk again)
+    int64_t j2 = cur + q;
+    for (; j2 < end; j2 += 2) {
+      const int32_t id = seen_items[j2];
+      if (id >= item_hi) break;
+      if (id >= item_lo && id < n_cand) {
+        const int sl = (int)((id >> 6) - st0);
+        const uint32_t pos = atomicAdd(&fillpos[sl], 1u);
+        const uint16_t code = (uint16_t)(ucode | (uint32_t)(id & 63));
+        if (pos < TK4_SLOT_CAP) {
+          reinterpret_cast<uint16_t*>(&tile[sl * TK4_SLOT_WORDS])[4 + pos] = code;
+        } else {
+          const uint64_t o = (uint64_t)ovbase[sl] + (pos - TK4_SLOT_CAP);
+          if (o < (uint64_t)row_cap) ovf[row_base + o] = code;
+          else s_lost = 1u;
+        }
+      }
+    }
+    if (j2 > end) j2 = end;
+    {   // first entry at or beyond item_hi = the smaller of the two stopping points (ascending list, stride 2)
+      const int64_t o1 = __shfl_xor(j2, 1, 2);
+      cur = (o1 < j2) ? o1 : j2;
+    }
+    __syncthreads();
+    // ---- write the slots out: 16 words (64 bytes) at a time, as far as the list reaches
+    uint4* out = reinterpret_cast<uint4*>(dst + st0 * TK4_SLOT_WORDS);
+    for (int i = t; i < nst * 16; i += 256) {
+      const int sl = i >> 4, part = (i >> 2) & 3;          // 4 uint4 = one 64-byte part
+      uint32_t n = tile[sl * TK4_SLOT_WORDS];
+      n = n < TK4_SLOT_CAP ? n : TK4_SLOT_CAP;
+      const int parts = (int)((8u + 2u * n + 63u) / 64u);   // header + entries, in 64-byte parts (>= 1)
+      if (part < parts) out[i] = reinterpret_cast<const uint4*>(tile)[i];
+    }
+    __syncthreads();
+  }
+  if (t == 0 && s_lost != 0u) atomicOr(flag, 1u);
+}
+
 // =============================================================================================================
 // host side
 // =============================================================================================================
@@ -448,16 +612,58 @@ bool cql_topk4_use(int d, int k, int64_t n_users, int64_t n_cand) {
   return mode == 2 || n_users >= 512 * 160;
 }
 
+bool cql_topk4_lists_on() {
+  static const bool on = !(getenv("CQL_TOPK4_LISTS") && getenv("CQL_TOPK4_LISTS")[0] == '0');     // A/B knob
+  return on;
+}
+
+// does a launch of this shape have room for its lists in the bitmap's space?
+bool cql_topk4_lists_fit(int64_t n_users, int64_t n_cand, int64_t space_bytes) {
+  return tk4_lists_carve(nullptr, space_bytes, n_users, n_cand).row_cap >= 4096;
+}
+
+// entry lists of the users' seen items into `space` (the bitmap's space, space_bytes of it); *flag (outside that space)
+// = 0: the scoring kernel takes the lists; 1: they did not fit, the caller's bitmap builder runs (under the same word)
+int cql_topk4_seen_lists(const int64_t* seen_off, const int32_t* seen_items, const int32_t* seen_rows, int64_t n_users,
+                         int64_t n_cand, void* space, int64_t space_bytes, uint32_t* flag, hipStream_t s) {
+  const Tk4Lists L = tk4_lists_carve(space, space_bytes, n_users, n_cand);
+  CQL_REQUIRE(L.row_cap >= 4096, "topk4_seen_lists: no room for the lists");
+  if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) {
+    cql_set_error("topk4_seen_lists: hipMemsetAsync failed");
+    return CQLREC_ERR_HIP;
+  }
+  hipLaunchKernelGGL(tk4_lists_kernel, dim3((unsigned)L.rows), dim3(256), 0, s, seen_off, seen_items, seen_rows, n_users, n_cand,
+                     (n_cand + 63) / 64, L.slots, L.ovf, L.row_cap, flag);
+  CQL_LAUNCH_CHECK("topk4_seen_lists");
+  return CQLREC_OK;
+}
+
+// a.seen_lists set (with a.guard = the builder's word): both forms are enqueued, the word picks one
 int cql_topk4_run(const QTk2Args& a, hipStream_t s) {
   constexpr int smem = Tk4Cfg<128>::SMEM;
   static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
   bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int64_t rblks = (a.n_users + 511) / 512;
-  hipLaunchKernelGGL((qtopk4_kernel<128>), dim3((unsigned)(rblks * a.nsplit)), dim3(256), smem, s, a);
+  const dim3 grid((unsigned)(rblks * a.nsplit));
+  if (a.seen_lists != nullptr && a.guard != nullptr) {
+    QTk2Args b = a;
+    b.seen_lists_ovf = tk4_lists_carve((void*)a.seen_lists, 1ll << 40, a.n_users, a.n_cand).ovf;
+    b.guard_want = 0;
+    hipLaunchKernelGGL((qtopk4_kernel<128, true>), grid, dim3(256), smem, s, b);
+    b.guard_want = 1;
+    b.seen_lists = nullptr;
+    hipLaunchKernelGGL((qtopk4_kernel<128, false>), grid, dim3(256), smem, s, b);
+  } else {
+    QTk2Args b = a;
+    b.guard = nullptr;
+    b.seen_lists = nullptr;
+    hipLaunchKernelGGL((qtopk4_kernel<128, false>), grid, dim3(256), smem, s, b);
+  }
   CQL_LAUNCH_CHECK("qtopk4");
   return CQLREC_OK;
 }

@@ -741,6 +741,27 @@ static bool tk_uses_topk2(int32_t d, int32_t k, int64_t n_cand, const int32_t* i
   return !tk2_off && !fused_off && !force_generic0 && item_ids == nullptr && cql_topk2_supported(d, k, n_cand);
 }
 
+extern "C" int cqlrec_topk_seen_form(const void* ws, int64_t n_users, int64_t n_cand, int32_t d, int32_t k, int32_t* out,
+                                     cqlrec_stream stream) {
+  CQL_REQUIRE(ws && out && n_users > 0 && n_cand > 0, "topk_seen_form: bad arguments");
+  *out = -1;
+  if (!tk_uses_topk2(d, k, n_cand, nullptr)) return CQLREC_OK;
+  int ns;
+  int64_t sr;
+  cql_topk2_split(n_users, n_cand, &ns, &sr);
+  const uint32_t* bits = (const uint32_t*)((const char*)ws + align256((int64_t)ns * n_users * 2 * QS_TOPK_K * 8));
+  const uint32_t* word = cql_topk2_lists_word(bits, n_users, n_cand);
+  if (!word) return CQLREC_OK;
+  uint32_t v = 0;
+  if (hipMemcpyAsync(&v, word, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    cql_set_error("topk_seen_form: copying the word back failed");
+    return CQLREC_ERR_HIP;
+  }
+  *out = v ? 1 : 0;
+  return CQLREC_OK;
+}
+
 extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, const uint16_t* E_b, const float* b,
                                        int64_t n_cand, int32_t d, const int32_t* item_ids, const int64_t* seen_off,
                                        const int32_t* seen_items, const int32_t* seen_rows, int32_t k, void* ws,
@@ -789,6 +810,8 @@ extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, con
         if (rc != CQLREC_OK) return rc;
       }
       a2.seen_bits = bits;
+      a2.guard = cql_topk2_lists_word(bits, n_users, n_cand);
+      a2.seen_lists = a2.guard ? bits : nullptr;          // (the lists live in the bitmap's space)
     }
     {
       CqlProfScope prof(CQLREC_PH_TOPK_TILEMAX, s);
