@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void tk4_lists_kernel(const int64_t* __restric
     cur = seen_off[srow];
     end = seen_off[srow + 1];
   }
+  const int64_t first = cur;                // (an id repeated in the ascending list counts once: a list never exceeds 128 x 64)
   if (t == 0) { s_run = 0u; s_lost = 0u; }
   uint32_t* const dst = slots + (int64_t)blockIdx.x * nst_all * TK4_SLOT_WORDS;
   const uint64_t row_base = (uint64_t)blockIdx.x * (uint64_t)row_cap;
@@ -544,7 +545,8 @@ __global__ __launch_bounds__(256) void tk4_lists_kernel(const int64_t* __restric
     for (; j < end; j += 2) {
       const int32_t id = seen_items[j];
       if (id >= item_hi) break;
-      if (id >= item_lo && id < n_cand) atomicAdd(&tile[(int)((id >> 6) - st0) * TK4_SLOT_WORDS], 1u);
+      if (id >= item_lo && id < n_cand && !(j > first && seen_items[j - 1] == id))
+        atomicAdd(&tile[(int)((id >> 6) - st0) * TK4_SLOT_WORDS], 1u);
     }
     __syncthreads();
     // ---- where the long lists continue: exclusive prefix of the excess over the chunk's stages (one thread: <= 96 terms)
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256) void tk4_lists_kernel(const int64_t* __restric
     for (; j2 < end; j2 += 2) {
       const int32_t id = seen_items[j2];
       if (id >= item_hi) break;
-      if (id >= item_lo && id < n_cand) {
+      if (id >= item_lo && id < n_cand && !(j2 > first && seen_items[j2 - 1] == id)) {
         const int sl = (int)((id >> 6) - st0);
         const uint32_t pos = atomicAdd(&fillpos[sl], 1u);
         const uint16_t code = (uint16_t)(ucode | (uint32_t)(id & 63));

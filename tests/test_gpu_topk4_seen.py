@@ -47,6 +47,9 @@ def _case(kind):
         keys.append((np.arange(n, dtype=np.int64)[:, None] * NN + half[None, :]).ravel())
     key = np.unique(np.concatenate(keys))
     rows, items = key // NN, (key % NN).astype(np.int32)
+    if kind == "popular":               # ids repeated in a list (still ascending) count once
+        rep = np.where(rows < 300, 2, 1)
+        rows, items = np.repeat(rows, rep), np.repeat(items, rep)
     seen_off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(np.bincount(rows, minlength=n), out=seen_off[1:])
     for j, u in enumerate(us):
