@@ -344,9 +344,9 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
   auto lists_step = [&](int gp) __attribute__((always_inline)) {
     lds_u8* const mW = (lds_u8*)smem + boff_c + C::STAGE_BYTES + T::STRIP + wave * 1024;
     const lds_u8* const stg = (const lds_u8*)smem + T::RING + T::QUEUES + (buf_c * 4 + wave) * 256;
-    auto set_bit = [&](uint32_t code) __attribute__((always_inline)) {
-      __hip_atomic_fetch_or((lds_u32_4*)(mW + (code >> 6) * 8 + ((code >> 5) & 1u) * 4), 1u << (code & 31u),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    auto set_bit = [&](uint32_t code) __attribute__((always_inline)) {      // word (user, tile) = code >> 5, bit = code & 31
+      __hip_atomic_fetch_or((lds_u32_4*)(mW + ((code >> 5) << 2)), 1u << (code & 31u), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     if (gp == 0) {
       ls_n = has_seen ? *(const lds_u32_4*)(stg) : 0u;
@@ -356,8 +356,8 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
       ls_n = ls_n < 8192u ? ls_n : 8192u;     // (128 users x 64 items: no list is longer; bounds the loop below whatever was read)
     } else if (gp == 2 || gp == 3) {
       const uint32_t n_slot = ls_n < (uint32_t)TK4_SLOT_CAP ? ls_n : (uint32_t)TK4_SLOT_CAP;
-      const uint32_t idx = 2u * (uint32_t)lane - 4u + (uint32_t)(gp - 2);     // lanes 0, 1 hold the header
-      if (lane >= 2 && idx < n_slot) set_bit((ls_e2 >> (16 * (gp - 2))) & 0xFFFFu);
+      const uint32_t idx = 2u * (uint32_t)lane - 4u + (uint32_t)(gp - 2);     // lanes 0, 1 hold the header: idx wraps, never < n_slot
+      if (idx < n_slot) set_bit((ls_e2 >> (16 * (gp - 2))) & 0xFFFFu);
     } else if (gp == 4) {
       if (__builtin_expect(ls_n > (uint32_t)TK4_SLOT_CAP, 0)) {      // a stage of popular items: the rest, from global memory
         const uint32_t ovf0 = *(const lds_u32_4*)(stg + 4);
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void tk4_lists_kernel(const int64_t* __restric
                                                         uint16_t* __restrict__ ovf, int64_t row_cap, uint32_t* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) uint32_t tile[TK4_LCH * TK4_SLOT_WORDS];     // the chunk's slots
   __shared__ uint32_t fillpos[TK4_LCH], ovbase[TK4_LCH];
-  __shared__ uint32_t s_run, s_lost;
+  __shared__ uint32_t s_run, s_lost, s_w0;
   const int t = threadIdx.x, user = t >> 1, q = t & 1;
   const int64_t u = (int64_t)blockIdx.x * 128 + user;
   int64_t cur = 0, end = 0;                 // this user's entries not yet placed (kept in step by its two threads)
@@ -549,16 +549,32 @@ __global__ __launch_bounds__(256) void tk4_lists_kernel(const int64_t* __restric
         atomicAdd(&tile[(int)((id >> 6) - st0) * TK4_SLOT_WORDS], 1u);
     }
     __syncthreads();
-    // ---- where the long lists continue: exclusive prefix of the excess over the chunk's stages (one thread: <= 96 terms)
-    if (t == 0) {
-      uint32_t run = s_run;
-      for (int i = 0; i < nst; ++i) {
-        const uint32_t n = tile[i * TK4_SLOT_WORDS];
-        ovbase[i] = run;
-        tile[i * TK4_SLOT_WORDS + 1] = (uint32_t)(row_base + run);
-        run += n > TK4_SLOT_CAP ? n - TK4_SLOT_CAP : 0u;
+    // ---- where the long lists continue: exclusive prefix of the excess over the chunk's stages (two waves, shuffles)
+    static_assert(TK4_LCH <= 128, "the prefix below uses two waves");
+    {
+      const int lane_ = t & 63;
+      uint32_t ex = 0u;
+      if (t < nst) {
+        const uint32_t n = tile[t * TK4_SLOT_WORDS];
+        ex = n > TK4_SLOT_CAP ? n - TK4_SLOT_CAP : 0u;
       }
-      s_run = run;
+      uint32_t inc = ex;
+      if (t < 128) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = __shfl_up(inc, o);
+          if (lane_ >= o) inc += v;
+        }
+        if (t == 63) s_w0 = inc;          // total of the first wave
+      }
+      __syncthreads();
+      if (t < nst) {
+        const uint32_t excl = s_run + inc - ex + (t >= 64 ? s_w0 : 0u);
+        ovbase[t] = excl;
+        tile[t * TK4_SLOT_WORDS + 1] = (uint32_t)(row_base + excl);
+      }
+      __syncthreads();
+      if (t == 127) s_run += inc + s_w0;  // (lane 63 of the second wave: its inclusive sum + the first wave's total)
     }
     __syncthreads();
     // ---- place the entries (the same walk again)
