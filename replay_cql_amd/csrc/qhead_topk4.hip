@@ -15,7 +15,9 @@
 //  * the per-lane candidate queues shrink from 24 to 12 entries (16 queues of 6 KiB per block instead of 8 of 12 KiB): the
 //    slow path walks the quads that hold a candidate in a RUN-TIME loop with one merge site in it (the queue is merged as
 //    soon as a lane holds more than 8 keys, a quad adds at most 4), instead of one straight-line scan behind one merge site;
-//  * the seen words of a wave's 128 users are one full 1 KiB LDS-DMA piece per stage (two 64-user blocks of the bitmap).
+//  * the seen words of a wave's 128 users are 1 KiB of mask words in LDS per stage: streamed in as one LDS-DMA piece
+//    (two 64-user blocks of the bitmap), or -- LISTS, the default -- expanded by the wave from a 256-byte list of the
+//    stage's seen (user, item) cells (tk4_lists_kernel, at the end of this file), which spares the 1.6 GB bitmap.
 #include <stdlib.h>
 #include <type_traits>
 #include "qhead_de_common.h"
