@@ -124,7 +124,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, off, items, rew, budget_s=12.0):
+def cpu_baseline(cfg, off, items, rew, budget_s=20.0):
     """Oracle (numpy restatement, multi-threaded BLAS) on the host cores: identical algorithm, identical batch.
     Returns the baseline object and what the parity check needs (initial parameters, per-step losses, top-K)."""
     import numpy as np

@@ -567,7 +567,9 @@ int cql_topk2_seen_bits(const int64_t* seen_off, const int32_t* seen_items, cons
     if (rc != CQLREC_OK) return rc;
     only_if = word;
   }
-  if (beside_scoring)
+  // (as the fall-back behind the lists it returns at once nearly always: the small-tile form, whose 2 048 blocks are
+  // handed out in a third of the time -- 8 instead of 23 us on the critical path of every launch)
+  if (beside_scoring || only_if != nullptr)
     hipLaunchKernelGGL(topk2_seen_bits_kernel<12>, dim3((unsigned)((n_users + 63) / 64)), dim3(256), 0, s, seen_off,
                        seen_items, seen_rows, n_users, n_cand, (n_cand + 63) / 64, bits, only_if);
   else

@@ -672,12 +672,16 @@ int cql_topk4_run(const QTk2Args& a, hipStream_t s) {
   const dim3 grid((unsigned)(rblks * a.nsplit));
   if (a.seen_lists != nullptr && a.guard != nullptr) {
     QTk2Args b = a;
-    b.seen_lists_ovf = tk4_lists_carve((void*)a.seen_lists, 1ll << 40, a.n_users, a.n_cand).ovf;
-    b.guard_want = 0;
-    hipLaunchKernelGGL((qtopk4_kernel<128, true>), grid, dim3(256), smem, s, b);
+    // the bitmap form FIRST: nearly always it returns at once, and in front of the real launch its blocks (each a whole
+    // CU's LDS and registers) are handed out to an idle chip in ~4 us; behind it they waited for the real blocks to
+    // leave (35 us on average, on the critical path of every launch)
     b.guard_want = 1;
     b.seen_lists = nullptr;
     hipLaunchKernelGGL((qtopk4_kernel<128, false>), grid, dim3(256), smem, s, b);
+    b.seen_lists = a.seen_lists;
+    b.seen_lists_ovf = tk4_lists_carve((void*)a.seen_lists, 1ll << 40, a.n_users, a.n_cand).ovf;
+    b.guard_want = 0;
+    hipLaunchKernelGGL((qtopk4_kernel<128, true>), grid, dim3(256), smem, s, b);
   } else {
     QTk2Args b = a;
     b.guard = nullptr;
