@@ -458,6 +458,10 @@ class CQLCore:
         losses = torch.zeros(max(n_batches, 1), dtype=torch.float32, device=self.device)
         for i in range(n_batches):
             N.check(self.lib.cqlrec_train_step_forward(C.byref(c), i, _ptr(losses[i:i + 1]), _stream()), "eval forward")
+        # The forward phase also sorts the pairs of a backward that never comes here, on a library stream that only the
+        # backward joins: those kernels read THIS log (o, it), which dies with this frame -- the whole device must be idle
+        # before it does (a sync of the current stream alone let them read freed memory: a GPU fault, timing permitting).
+        torch.cuda.synchronize(self.device)
         return float(losses[:n_batches].mean().item()) if n_batches else float("nan")
 
     def views(self, step: Optional[int] = None) -> Dict[str, torch.Tensor]:

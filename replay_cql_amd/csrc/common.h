@@ -58,6 +58,10 @@ struct CqlProfScope {
 int cql_encoder_bwd_parts(const float* dH, const uint16_t* z_b, const uint16_t* h0_b, const uint16_t* W1_b,
                           const uint16_t* W2_b, int64_t rows, int32_t d, void* ws, int64_t ws_bytes, float* g_W1, float* g_b1,
                           float* g_W2, float* g_b2, float* dh0, int parts, hipStream_t s);
+// misc.hip: cqlrec_td_loss in two launches (coefficients by many blocks; the loss value by one, off the critical path)
+int cql_td_coef(const float* q_a, const float* lse, const float* q_targ, const float* rew, const float* done, int32_t batch,
+                float gamma, float alpha, float inv_batch, float* coef, float* y, float* term, hipStream_t s);
+int cql_td_loss_sum(const float* term, int32_t batch, float inv_batch, float* loss_out, hipStream_t s);
 int64_t cql_onehot_ws_bytes(int64_t batch, int32_t d);
 int cql_onehot_prepare(const int32_t* act, int64_t batch, int64_t n_items, int32_t d, void* ws, int64_t ws_bytes,
                        hipStream_t s);

@@ -675,6 +675,53 @@ __global__ __launch_bounds__(256) void td_loss_kernel(const float* __restrict__ 
   if (threadIdx.x == 0 && loss_out) *loss_out = red[0] * inv_batch;
 }
 
+// The same in two launches for the step driver: the dQ coefficients -- all the backward needs -- by as many blocks as
+// there are rows to spread, and the loss VALUE (which nothing in the step waits for) summed by one block from the terms
+// the first launch leaves, in td_loss_kernel's order: coefficients, targets and loss bit-identical to the one launch.
+__global__ __launch_bounds__(256) void td_coef_kernel(const float* __restrict__ q_a, const float* __restrict__ lse,
+                                                      const float* __restrict__ q_targ, const float* __restrict__ rew,
+                                                      const float* __restrict__ done, int batch, float gamma, float alpha,
+                                                      float inv_batch, float* __restrict__ coef, float* __restrict__ y,
+                                                      float* __restrict__ term) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= batch) return;
+  const float yy = rew[b] + gamma * (1.0f - done[b]) * q_targ[b];
+  const float delta = q_a[b] - yy;
+  term[b] = 0.5f * delta * delta + alpha * (lse[b] - q_a[b]);
+  coef[b] = (delta - alpha) * inv_batch;
+  if (y) y[b] = yy;
+}
+__global__ __launch_bounds__(256) void td_loss_sum_kernel(const float* __restrict__ term, int batch, float inv_batch,
+                                                          float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < batch; b += 256) s += term[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss_out = red[0] * inv_batch;
+}
+int cql_td_coef(const float* q_a, const float* lse, const float* q_targ, const float* rew, const float* done, int32_t batch,
+                float gamma, float alpha, float inv_batch, float* coef, float* y, float* term, hipStream_t s) {
+  CQL_REQUIRE(q_a && lse && q_targ && rew && done && coef && term, "td_coef: NULL pointer");
+  CQL_REQUIRE(batch > 0, "td_coef: batch=%d", batch);
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  hipLaunchKernelGGL(td_coef_kernel, dim3((unsigned)cql_ceil_div(batch, 256)), dim3(256), 0, s, q_a, lse, q_targ, rew, done,
+                     batch, gamma, alpha, inv_batch, coef, y, term);
+  CQL_LAUNCH_CHECK("td_coef");
+  return CQLREC_OK;
+}
+int cql_td_loss_sum(const float* term, int32_t batch, float inv_batch, float* loss_out, hipStream_t s) {
+  CQL_REQUIRE(term && loss_out && batch > 0, "td_loss_sum: bad arguments");
+  CqlProfScope prof(CQLREC_PH_QHEAD_SMALL, s);
+  hipLaunchKernelGGL(td_loss_sum_kernel, dim3(1), dim3(256), 0, s, term, batch, inv_batch, loss_out);
+  CQL_LAUNCH_CHECK("td_loss_sum");
+  return CQLREC_OK;
+}
+
 extern "C" int cqlrec_td_loss(const float* q_a, const float* lse, const float* q_targ, const float* rew,
                               const float* done, int32_t batch, float gamma, float alpha, float inv_batch, float* coef,
                               float* y, float* loss_out, cqlrec_stream stream) {

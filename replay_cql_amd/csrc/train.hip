@@ -50,7 +50,7 @@ struct Carve {
 
 struct StepWs {
   int32_t *users, *tpos, *act, *a_star;
-  float *rew, *done, *q_a, *lse, *nlse2, *nlse_nat, *q_targ, *y, *coef, *maxv, *loss;
+  float *rew, *done, *q_a, *lse, *nlse2, *nlse_nat, *q_targ, *y, *coef, *maxv, *loss, *term;
   float *h0_s, *dH, *dh0;
   uint16_t *h0b, *zb, *hb, *h0b_t, *zb_t, *hb_t;
   void *ws_q, *ws_q2, *ws_qb, *ws_qb2, *ws_enc, *ws_gb, *ws_oh;
@@ -76,6 +76,7 @@ void carve_small(Carve& c, StepWs& w, int32_t B, int32_t d) {
   w.coef = c.take<float>(B);
   w.maxv = c.take<float>(B);
   w.loss = c.take<float>(64);
+  w.term = c.take<float>(B);      // per-transition loss terms (cql_td_coef -> cql_td_loss_sum)
   w.h0_s = c.take<float>((int64_t)B * d);
   w.dH = c.take<float>((int64_t)B * d);
   w.dh0 = c.take<float>((int64_t)B * d);
@@ -393,8 +394,16 @@ static bool dh_early() {
 }
 // early_items (a stream) + early_fix: the long item-side kernel of THIS step is launched on that stream as soon as the fused
 // forward has produced -lse (it needs nothing from the loss), see backward_items_impl
+// the loss VALUE of `step` from the terms its forward left (nothing in the step waits for it)
+int loss_sum_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, hipStream_t on) {
+  StepWs w = carve_step(c->ws, c->batch, c->layout.n_items, c->layout.d, c->window, step);
+  const float inv_batch = 1.0f / ((float)c->batch * (float)c->world);
+  return cql_td_loss_sum(w.term, c->batch, inv_batch, loss_out ? loss_out : w.loss, on);
+}
+// loss_sum_deferred != NULL: the loss terms are left for the caller's loss_sum_impl (on a stream that has slack)
 int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlrec_stream stream, hipEvent_t eout_ready,
-                 hipEvent_t presampled = nullptr, hipStream_t early_items = nullptr, CqlAdamFix* early_fix = nullptr) {
+                 hipEvent_t presampled = nullptr, hipStream_t early_items = nullptr, CqlAdamFix* early_fix = nullptr,
+                 bool* loss_sum_deferred = nullptr) {
   const cqlrec_layout& L = c->layout;
   const int32_t B = c->batch, d = L.d, W = c->window;
   const int64_t N = L.n_items;
@@ -484,8 +493,10 @@ int forward_impl(const cqlrec_train_ctx* c, uint64_t step, float* loss_out, cqlr
   }
   // loss + dQ coefficients
   const float inv_batch = 1.0f / ((float)B * (float)c->world);
-  CQL_TRY(cqlrec_td_loss(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, (float)c->gamma, (float)c->alpha, inv_batch, w.coef, w.y,
-                         loss_out ? loss_out : w.loss, stream));
+  CQL_TRY(cql_td_coef(w.q_a, w.lse, w.q_targ, w.rew, w.done, B, (float)c->gamma, (float)c->alpha, inv_batch, w.coef, w.y,
+                      w.term, s));
+  if (loss_sum_deferred) *loss_sum_deferred = true;
+  else CQL_TRY(cql_td_loss_sum(w.term, B, inv_batch, loss_out ? loss_out : w.loss, s));
   if (g_mark_phase == 2) mark(MK_NEXT_LOSS, s);
   return CQLREC_OK;
 }
@@ -684,7 +695,11 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
     SideStream& ss0 = side_stream();
     const bool early = early_de && ss0.ok && ss0.s && !onehot_atomic();
     CqlAdamFix fix = {};
-    CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled, early ? ss0.s : nullptr, &fix));
+    // the sum of the loss terms goes to the head of the sample-ahead stream (it has slack) when that stream is used
+    bool sum_deferred = false;
+    const bool can_defer = ss0.ok && ss0.s3 && i + 1 < n_steps;
+    CQL_TRY(forward_impl(c, step, loss_out ? loss_out + i : nullptr, stream, pending, sampled, early ? ss0.s : nullptr, &fix,
+                         can_defer ? &sum_deferred : nullptr));
     pending = sampled = nullptr;
     if (g_marks_on && n_steps >= 4) {   // marks: backward of step n/2, forward of step n/2 + 1
       if (i == n_steps / 2) g_mark_phase = 1;
@@ -694,6 +709,10 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
     if (g_mark_phase == 1) mark(MK_LOSS, s);
     if (ss.ok && hipEventRecord(ss.loss, s) == hipSuccess) {
       if (i + 1 < n_steps && hipStreamWaitEvent(ss.s3, ss.loss, 0) == hipSuccess) {
+        if (sum_deferred) {
+          CQL_TRY(loss_sum_impl(c, step, loss_out ? loss_out + i : nullptr, ss.s3));
+          sum_deferred = false;
+        }
         // the next step's transitions depend on (seed, step) only: sample them now, on a stream of their own, and sort
         // the pairs its backward will need (two radix sorts, ~35 small launches) behind that
         CQL_TRY(sample_ahead(c, step + 1, (cqlrec_stream)ss.s3, ss.presample));
@@ -701,6 +720,7 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
         if (g_mark_phase == 1) mark(MK_SORT_NEXT, ss.s3);
         sampled = ss.presample;
       }
+      if (sum_deferred) CQL_TRY(loss_sum_impl(c, step, loss_out ? loss_out + i : nullptr, s));      // (s3 could not take it)
       CQL_HIP_TRY(hipStreamWaitEvent(ss.s, ss.loss, 0), "train_steps");
       // sparse scatter, then the long dE_out kernel; the sum of its cut pieces is left to the item-side Adam below
       static const int defer_fixup = !(getenv("CQL_DEFER_FIXUP") && getenv("CQL_DEFER_FIXUP")[0] == '0');
@@ -738,6 +758,7 @@ extern "C" int cqlrec_train_steps(const cqlrec_train_ctx* c, uint64_t step0, int
       if (g_mark_phase == 1) { mark(MK_ADAM_OUT, ss.s); g_mark_phase = 2; }
       pending = ss.eout;
     } else {
+      if (sum_deferred) CQL_TRY(loss_sum_impl(c, step, loss_out ? loss_out + i : nullptr, s));
       CQL_TRY(backward_rest_impl(c, step, stream));
       CQL_TRY(backward_items_impl(c, step, stream));
       CQL_TRY(cqlrec_train_step_update_range(c, step, 0, L.total, stream));
