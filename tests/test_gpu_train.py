@@ -254,3 +254,28 @@ def test_phased_step_equals_fused_step():
     assert torch.equal(core_a.theta, core_b.theta) and torch.equal(core_a.target, core_b.target)
     assert torch.count_nonzero(core_b.grads).item() == 0
     assert torch.equal(core_b.theta_b.float(), core_b.theta.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("phased", [False, True])
+def test_early_item_side_launch_changes_no_bit(phased):
+    """The long dE_out kernel launched behind the fused forward (default, in the pipelined single-rank driver and -- through
+    cqlrec_train_step_forward_early_items -- in the data-parallel step loop) against the old order, behind the loss
+    (CQL_EARLY_DE=0): losses, parameters, Adam moments, target net and shadows bit-identical after 6 steps + one single
+    step.  The knob is read once per process: two child processes (tools/train_digest.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    outs = []
+    for knob in ("1", "0"):
+        env = dict(os.environ, CQL_EARLY_DE=knob)
+        cmd = [sys.executable, str(root / "tools" / "train_digest.py"), "--d", "128", "--items", "20000", "--steps", "6"]
+        if phased:
+            cmd.append("--phased")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["losses"] == outs[1]["losses"]
+    assert outs[0]["state_sha256"] == outs[1]["state_sha256"]
