@@ -202,3 +202,24 @@ def test_cfg1_ml1m_shape_fit_predict_matches_oracle():
         bad2, _ = topk_rule_violations(gi[bad], gv[bad], sizes[bad], Q2, K)
         assert bad2.size == 0, bad[bad2]
     assert swaps <= U // 50, swaps
+
+
+def test_cfg3_seen_entry_lists_equal_the_bitmap_for_every_user():
+    """qtopk4_kernel's two seen-filter forms over the whole 150 205-user shard in the bench's chunking (131 072 + 19 133),
+    model trained 30 steps: ids, scores and counts of EVERY user bit-identical (SHA-256 of the three outputs).  The knob
+    CQL_TOPK4_LISTS is read once per process: two child processes (tools/topk_digest.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    outs = []
+    for knob in ("1", "0"):
+        env = dict(os.environ, CQL_TOPK4_LISTS=knob)
+        r = subprocess.run([sys.executable, str(root / "tools" / "topk_digest.py")], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["cnt_min"] == K
+    assert outs[0] == outs[1]
