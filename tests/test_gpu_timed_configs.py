@@ -204,10 +204,11 @@ def test_cfg1_ml1m_shape_fit_predict_matches_oracle():
     assert swaps <= U // 50, swaps
 
 
-def test_cfg3_seen_entry_lists_equal_the_bitmap_for_every_user():
-    """qtopk4_kernel's two seen-filter forms over the whole 150 205-user shard in the bench's chunking (131 072 + 19 133),
-    model trained 30 steps: ids, scores and counts of EVERY user bit-identical (SHA-256 of the three outputs).  The knob
-    CQL_TOPK4_LISTS is read once per process: two child processes (tools/topk_digest.py)."""
+def test_cfg3_three_forms_of_the_scoring_pass_agree_for_every_user():
+    """qtopk4_kernel with entry lists (default), qtopk4_kernel with the bitmap (CQL_TOPK4_LISTS=0) and qtopk2_kernel
+    (CQL_TOPK4=0) over the whole 150 205-user shard in the bench's chunking (131 072 + 19 133), model trained 30 steps:
+    ids, scores and counts of EVERY user bit-identical (SHA-256 of the three outputs).  The knobs are read once per
+    process: three child processes (tools/topk_digest.py)."""
     import json
     import os
     import subprocess
@@ -215,11 +216,11 @@ def test_cfg3_seen_entry_lists_equal_the_bitmap_for_every_user():
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     outs = []
-    for knob in ("1", "0"):
-        env = dict(os.environ, CQL_TOPK4_LISTS=knob)
+    for knobs in ({}, {"CQL_TOPK4_LISTS": "0"}, {"CQL_TOPK4": "0"}):
+        env = dict(os.environ, **knobs)
         r = subprocess.run([sys.executable, str(root / "tools" / "topk_digest.py")], env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0]["cnt_min"] == K
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
