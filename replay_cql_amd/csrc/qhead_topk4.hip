@@ -76,8 +76,11 @@ __device__ __forceinline__ void tk4_mfma_acc(f32x16& acc, const bf16x8& a_frag, 
 // LISTS: the seen filter arrives as entry lists (tk4_lists_* below: one 256-byte slot per wave of 128 users and stage of
 // 64 items, longer lists continue in an overflow area) instead of the dense bitmap; the wave expands the list of a
 // stage into the same 1 KiB of mask words in LDS that the dense form streams in.
-template <int D, bool LISTS>
+// KC: list entries that are kept sorted (10 for k <= 10, else 16): an insertion costs ~9 instructions per entry it
+// passes, and what falls off position KC - 1 of a (slice, user, lane half) list cannot be among that list's best k.
+template <int D, bool LISTS, int KC>
 __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
+  static_assert(KC == 10 || KC == 16, "lists of 10 or 16 sorted keys");
   // the two forms are launched one behind the other; the word the list builder leaves picks one on the device
   if (a.guard != nullptr && ((*a.guard != 0u) != (a.guard_want != 0))) return;
   using T = Tk4Cfg<D>;
@@ -197,16 +200,20 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
     unsigned long long lst[TK4_K];
 #pragma unroll
     for (int j = 0; j < TK4_K; ++j) {
-      uint32_t lo, hi;
-      TK4_AR(lo, la[g][2 * j]);
-      TK4_AR(hi, la[g][2 * j + 1]);
-      lst[j] = ((unsigned long long)hi << 32) | lo;
+      if (j < KC) {
+        uint32_t lo, hi;
+        TK4_AR(lo, la[g][2 * j]);
+        TK4_AR(hi, la[g][2 * j + 1]);
+        lst[j] = ((unsigned long long)hi << 32) | lo;
+      } else {
+        lst[j] = 0ull;         // (never holds a key: the registers behind it stay zero from the start)
+      }
     }
 #pragma unroll 1
     for (int e = 0; __builtin_amdgcn_ballot_w64(e < cnt[g]) != 0; ++e) {
       unsigned long long kx = (e < cnt[g]) ? *(const lds_u64_4*)(qb + 512 * e) : 0ull;
 #pragma unroll
-      for (int j = 0; j < TK4_K; ++j) {       // insertion into the sorted list: keys are distinct
+      for (int j = 0; j < KC; ++j) {       // insertion into the sorted list: keys are distinct
         const bool gt = kx > lst[j];
         const unsigned long long hi_ = gt ? kx : lst[j];
         kx = gt ? lst[j] : kx;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < TK4_K; ++j) {
+    for (int j = 0; j < KC; ++j) {
       TK4_AW(la[g][2 * j], (uint32_t)lst[j]);
       TK4_AW(la[g][2 * j + 1], (uint32_t)(lst[j] >> 32));
     }
@@ -664,12 +671,25 @@ int cql_topk4_run(const QTk2Args& a, hipStream_t s) {
   static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
   bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, false, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, true, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk4_kernel<128, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int64_t rblks = (a.n_users + 511) / 512;
   const dim3 grid((unsigned)(rblks * a.nsplit));
+  static const bool force16 = getenv("CQL_TOPK4_KC") && atoi(getenv("CQL_TOPK4_KC")) == 16;      // A/B knob
+  const bool kc12 = a.k <= 10 && !force16;      // KC = 10
+  auto launch = [&](const QTk2Args& b, bool lists) {
+    if (lists) {
+      if (kc12) hipLaunchKernelGGL((qtopk4_kernel<128, true, 10>), grid, dim3(256), smem, s, b);
+      else hipLaunchKernelGGL((qtopk4_kernel<128, true, 16>), grid, dim3(256), smem, s, b);
+    } else {
+      if (kc12) hipLaunchKernelGGL((qtopk4_kernel<128, false, 10>), grid, dim3(256), smem, s, b);
+      else hipLaunchKernelGGL((qtopk4_kernel<128, false, 16>), grid, dim3(256), smem, s, b);
+    }
+  };
   if (a.seen_lists != nullptr && a.guard != nullptr) {
     QTk2Args b = a;
     // the bitmap form FIRST: nearly always it returns at once, and in front of the real launch its blocks (each a whole
@@ -677,16 +697,16 @@ int cql_topk4_run(const QTk2Args& a, hipStream_t s) {
     // leave (35 us on average, on the critical path of every launch)
     b.guard_want = 1;
     b.seen_lists = nullptr;
-    hipLaunchKernelGGL((qtopk4_kernel<128, false>), grid, dim3(256), smem, s, b);
+    launch(b, false);
     b.seen_lists = a.seen_lists;
     b.seen_lists_ovf = tk4_lists_carve((void*)a.seen_lists, 1ll << 40, a.n_users, a.n_cand).ovf;
     b.guard_want = 0;
-    hipLaunchKernelGGL((qtopk4_kernel<128, true>), grid, dim3(256), smem, s, b);
+    launch(b, true);
   } else {
     QTk2Args b = a;
     b.guard = nullptr;
     b.seen_lists = nullptr;
-    hipLaunchKernelGGL((qtopk4_kernel<128, false>), grid, dim3(256), smem, s, b);
+    launch(b, false);
   }
   CQL_LAUNCH_CHECK("qtopk4");
   return CQLREC_OK;
