@@ -226,16 +226,21 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
       TK4_AW(la[g][2 * j + 1], (uint32_t)(lst[j] >> 32));
     }
     cnt[g] = 0;
-    const unsigned long long m0 = kb0 ? ~0ull : 0ull, m1 = kb1 ? ~0ull : 0ull, m2 = kb2 ? ~0ull : 0ull,
-                             m3 = kb3 ? ~0ull : 0ull;
-    unsigned long long t8[8], t4[4], t2[2];
+    unsigned long long kk;
+    if (kth == KC - 1) {       // (wave-uniform) the usual case, k = the number of keys kept sorted: the last of them
+      kk = lst[KC - 1];
+    } else {                   // any other k: a 4-level select tree over the bits of k - 1 (~90 instructions)
+      const unsigned long long m0 = kb0 ? ~0ull : 0ull, m1 = kb1 ? ~0ull : 0ull, m2 = kb2 ? ~0ull : 0ull,
+                               m3 = kb3 ? ~0ull : 0ull;
+      unsigned long long t8[8], t4[4], t2[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t8[j] = (lst[2 * j + 1] & m0) | (lst[2 * j] & ~m0);
+      for (int j = 0; j < 8; ++j) t8[j] = (lst[2 * j + 1] & m0) | (lst[2 * j] & ~m0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t4[j] = (t8[2 * j + 1] & m1) | (t8[2 * j] & ~m1);
+      for (int j = 0; j < 4; ++j) t4[j] = (t8[2 * j + 1] & m1) | (t8[2 * j] & ~m1);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) t2[j] = (t4[2 * j + 1] & m2) | (t4[2 * j] & ~m2);
-    const unsigned long long kk = (t2[1] & m3) | (t2[0] & ~m3);
+      for (int j = 0; j < 2; ++j) t2[j] = (t4[2 * j + 1] & m2) | (t4[2 * j] & ~m2);
+      kk = (t2[1] & m3) | (t2[0] & ~m3);
+    }
     const uint32_t okey = (uint32_t)(kk >> 32);
     const float own = (kk != 0ull) ? f32_from_order_key(okey) : -3.0e38f;
     const float own_up = (kk != 0ull) ? f32_from_order_key(okey + 1u) : -3.0e38f;
