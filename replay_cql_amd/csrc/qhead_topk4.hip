@@ -266,14 +266,26 @@ __global__ __launch_bounds__(256, 1) void qtopk4_kernel(QTk2Args a) {
     while (qmask != 0u) {
       const int q = __builtin_ctz(qmask);          // wave-uniform
       qmask &= qmask - 1u;
-      const bool q1 = q & 1, q2 = q & 2;
+      // the quad's four scores by bit-selects under two wave-uniform masks (3 v_bfi per element; `q1 ? a : b` on a
+      // run-time q became s_set_gpr_idx register indexing: 7 instructions per element)
       float e[4];
+#ifdef TK4_ABL_QUAD_SELECT      // A/B build: the selects as written first
+      const bool q1 = q & 1, q2 = q & 2;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const float lo = q1 ? acc[4 + jj] : acc[jj];
         const float hi = q1 ? acc[12 + jj] : acc[8 + jj];
         e[jj] = q2 ? hi : lo;
       }
+#else
+      const uint32_t m1 = (q & 1) ? 0xFFFFFFFFu : 0u, m2 = (q & 2) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t lo = (m1 & __float_as_uint(acc[4 + jj])) | (~m1 & __float_as_uint(acc[jj]));
+        const uint32_t hi = (m1 & __float_as_uint(acc[12 + jj])) | (~m1 & __float_as_uint(acc[8 + jj]));
+        e[jj] = __uint_as_float((m2 & hi) | (~m2 & lo));
+      }
+#endif
       if (__builtin_amdgcn_ballot_w64(cnt[g] > TK4_Q - 4) != 0) merge(G_);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
