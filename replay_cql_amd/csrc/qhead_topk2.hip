@@ -93,8 +93,11 @@ __device__ __forceinline__ float tk2_max3(float a, float b, float c) {
   return q;
 }
 
-template <int D>
+// KC: list entries that are kept sorted (10 for k <= 10, else 16; see qtopk4_kernel): what falls off position KC - 1 of a
+// (slice, user, lane half) list cannot be among that list's best k, and an insertion costs ~8 instructions per key passed.
+template <int D, int KC>
 __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
+  static_assert(KC == 10 || KC == 16, "lists of 10 or 16 sorted keys");
   using T = Tk2Cfg<D>;
   using C = typename T::C;
   constexpr int KS = C::KS;
@@ -201,16 +204,20 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
     unsigned long long lst[TK2_K];
 #pragma unroll
     for (int j = 0; j < TK2_K; ++j) {
-      uint32_t lo, hi;
-      TK2_AR(lo, la[g][2 * j]);
-      TK2_AR(hi, la[g][2 * j + 1]);
-      lst[j] = ((unsigned long long)hi << 32) | lo;
+      if (j < KC) {
+        uint32_t lo, hi;
+        TK2_AR(lo, la[g][2 * j]);
+        TK2_AR(hi, la[g][2 * j + 1]);
+        lst[j] = ((unsigned long long)hi << 32) | lo;
+      } else {
+        lst[j] = 0ull;         // (never holds a key: the registers behind it stay zero from the start)
+      }
     }
 #pragma unroll 1
     for (int e = 0; __builtin_amdgcn_ballot_w64(e < cnt[g]) != 0; ++e) {
       unsigned long long kx = (e < cnt[g]) ? *(const lds_u64*)(qb[g] + 512 * e) : 0ull;
 #pragma unroll
-      for (int j = 0; j < TK2_K; ++j) {       // insertion into the sorted list: keys are distinct
+      for (int j = 0; j < KC; ++j) {       // insertion into the sorted list: keys are distinct
         const bool gt = kx > lst[j];
         const unsigned long long hi_ = gt ? kx : lst[j];
         kx = gt ? lst[j] : kx;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void qtopk2_kernel(QTk2Args a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < TK2_K; ++j) {
+    for (int j = 0; j < KC; ++j) {
       TK2_AW(la[g][2 * j], (uint32_t)lst[j]);
       TK2_AW(la[g][2 * j + 1], (uint32_t)(lst[j] >> 32));
     }
@@ -586,11 +593,16 @@ int cql_topk2_run(const QTk2Args& a, int d, hipStream_t s) {
   static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
   bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)qtopk2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk2_kernel<128, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)qtopk2_kernel<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int64_t rblks = (a.n_users + 255) / 256;
-  hipLaunchKernelGGL((qtopk2_kernel<128>), dim3((unsigned)(rblks * a.nsplit)), dim3(256), smem, s, a);
+  static const bool force16 = getenv("CQL_TOPK4_KC") && atoi(getenv("CQL_TOPK4_KC")) == 16;      // A/B knob (both kernels)
+  if (a.k <= 10 && !force16)
+    hipLaunchKernelGGL((qtopk2_kernel<128, 10>), dim3((unsigned)(rblks * a.nsplit)), dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL((qtopk2_kernel<128, 16>), dim3((unsigned)(rblks * a.nsplit)), dim3(256), smem, s, a);
   CQL_LAUNCH_CHECK("qtopk2");
   return CQLREC_OK;
 }
