@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
   // QM_TOPK: per 32-user group the list of the QS_TOPK_K best admissible candidates of THIS lane's half of every tile
   // (sorted, best first; 0 = none), the pruning bound (the k-th best admissible score known for the user, shared by
   // the two lane halves), and a small LDS buffer of candidates that beat the bound since the last merge.
-  constexpr bool TOPK = (MODE == QM_TOPK);
+  constexpr bool TOPK = (MODE == QM_TOPK || MODE == QM_TOPK10);
+  constexpr int TKC = (MODE == QM_TOPK10) ? 10 : QS_TOPK_K;      // list entries kept sorted
   unsigned long long tk_lst[TOPK ? SPW : 1][TOPK ? QS_TOPK_K : 1];
   float tk_thr[TOPK ? SPW : 1];
   int tk_cnt[TOPK ? SPW : 1];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         const uint32_t c = ~(uint32_t)(key[e] & 0xFFFFFFFFull);
         unsigned long long kx = ((wd[e] >> (c & 31)) & 1u) ? 0ull : key[e];
 #pragma unroll
-        for (int j = 0; j < QS_TOPK_K; ++j) {       // insertion into the sorted list: keys are distinct
+        for (int j = 0; j < TKC; ++j) {       // insertion into the sorted list: keys are distinct
           const bool gt = kx > tk_lst[g][j];
           const unsigned long long hi_ = gt ? kx : tk_lst[g][j];
           kx = gt ? tk_lst[g][j] : kx;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
           st_a[g] = upd ? tmax : st_a[g];
           st_i[g] = upd ? (int)tile_row0 : st_i[g];
         }
-      } else if constexpr (MODE == QM_TOPK) {
+      } else if constexpr (TOPK) {
 #pragma unroll
         for (int g = 0; g < SPW; ++g) {
           float tmax = acc[g][0];
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256, MINW) void qstream_kernel(QArgs a) {
         a.part_a[pidx] = M;
         a.part_b[pidx] = Lsum;
       }
-    } else if constexpr (MODE == QM_TOPK) {
+    } else if constexpr (TOPK) {
       tk_merge(g);
       if (ok) {
         unsigned long long* dst = a.topk_keys + (((int64_t)split * a.n_res + row) * 2 + h) * QS_TOPK_K;
@@ -572,7 +573,7 @@ QSplit qs_choose_split(int64_t n_str, int64_t n_res, int spw, int unit_rows, int
 
 template <int D, int SPW, int MODE, int NBUF, int MINW>
 static void qs_launch_n(const QArgs& a, int64_t rblks, hipStream_t s) {
-  constexpr int smem = NBUF * QCfg<D>::BUF_BYTES + (MODE == QM_TOPK ? 4 * SPW * QS_TOPK_BUF * 64 * 8 : 0);
+  constexpr int smem = NBUF * QCfg<D>::BUF_BYTES + ((MODE == QM_TOPK || MODE == QM_TOPK10) ? 4 * SPW * QS_TOPK_BUF * 64 * 8 : 0);
   static bool attr_set_dev[CQL_MAX_DEVICES] = {};   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device
   bool& attr_set = attr_set_dev[cql_device_slot()];
   if (!attr_set) {
@@ -607,9 +608,9 @@ static int qs_launch_mode(const QArgs& a, int d, int64_t rblks, hipStream_t s) {
 
 static int qs_launch_switch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s);
 int qs_launch(int mode, const QArgs& a, int d, int64_t rblks, hipStream_t s) {
-  static const int phase_of[8] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
+  static const int phase_of[9] = {0, CQLREC_PH_QHEAD_LSE, CQLREC_PH_QHEAD_ARGMAX, CQLREC_PH_TOPK_TILEMAX,
                                   CQLREC_PH_QHEAD_BWD_DH, CQLREC_PH_QHEAD_BWD_DE, CQLREC_PH_QHEAD_LSE,
-                                  CQLREC_PH_TOPK_TILEMAX};
+                                  CQLREC_PH_TOPK_TILEMAX, CQLREC_PH_TOPK_TILEMAX};
   CqlProfScope prof(phase_of[mode], s);
   return qs_launch_switch(mode, a, d, rblks, s);
 }
@@ -629,6 +630,7 @@ static int qs_launch_switch(int mode, const QArgs& a, int d, int64_t rblks, hipS
       if (qs_spw_fwd(d) == 4) return qs_launch_mode<QM_TILEMAX, 4>(a, d, rblks, s);
       return qs_launch_mode<QM_TILEMAX, 2>(a, d, rblks, s);
     case QM_TOPK: return qs_launch_mode<QM_TOPK, 2>(a, d, rblks, s);
+    case QM_TOPK10: return qs_launch_mode<QM_TOPK10, 2>(a, d, rblks, s);
     case QM_BWD_DH: return qs_launch_mode<QM_BWD_DH, QS_SPW_BWD>(a, d, rblks, s);
     case QM_BWD_DE: return qs_launch_mode<QM_BWD_DE, QS_SPW_BWD>(a, d, rblks, s);
     case QM_LSE_DH: return qs_launch_mode<QM_LSE_DH, QS_SPW_BWD>(a, d, rblks, s);

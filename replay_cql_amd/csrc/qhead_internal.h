@@ -9,6 +9,7 @@
 #define QM_BWD_DE 5
 #define QM_LSE_DH 6         // forward logsumexp AND the softmax-weighted item sum (the soft part of dH) in one pass
 #define QM_TOPK 7           // running top-k (k <= 16) per user in the epilogue: no score or group maximum leaves the chip
+#define QM_TOPK10 8         // the same with only 10 of the 16 list entries kept sorted (k <= 10; see qtopk4_kernel's KC)
 #define QS_TOPK_K 16        // list length kept per (user, lane half, item slice)
 #define QS_TOPK_BUF 4       // candidates buffered per lane between two merges into the list
 

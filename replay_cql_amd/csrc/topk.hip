@@ -851,7 +851,7 @@ extern "C" int cqlrec_score_topk_phase(const uint16_t* H_b, int64_t n_users, con
     a.topk_k = k;
     a.seen_bits = bits;
     a.seen_w = W;
-    qs_launch(QM_TOPK, a, d, sp.rblks, s);
+    qs_launch(k <= 10 ? QM_TOPK10 : QM_TOPK, a, d, sp.rblks, s);      // k <= 10: only 10 list entries are kept sorted
     CqlProfScope prof(CQLREC_PH_TOPK_SELECT, s);
     tk_launch_merge((const unsigned long long*)ws, sp.nsplit, n_users, item_ids, (int)k, out_idx, out_val, out_cnt, s);
     CQL_LAUNCH_CHECK("score_topk (fused)");
